@@ -1,0 +1,900 @@
+/*
+ * oracle/bn254_ref.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the Groth16 proving hot path of the reference
+ * (aptos-labs/keyless-zk-proofs, vendored rapidsnark): BN254 Fq/Fr/Fq2
+ * Montgomery arithmetic, XYZZ curve arithmetic on G1/G2, Pippenger MSM,
+ * radix-2 NTT/iNTT, the prove() pipeline, zkey/wtns parsing and the proof
+ * JSON encoder.  It is the checker for the HIP path: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it.
+ *
+ * Parity pinning (see tests/test_oracle_*.py):
+ *   - raw Montgomery KATs held by the reference's own tests
+ *     (test_prover.cpp Fr_Rw_* / Fq_Rw_*), extracted to tests/golden/field_kats.json
+ *   - the reference's field sources compiled as they lie (oracle/_ref, build_ref.sh)
+ *     compared on random canonical inputs (this container only)
+ *   - alt_bn128_test.cpp KATs: F2 mul, G1 identities, r*G = inf on G1/G2,
+ *     2-point MSM with explicit expected output, 40000-point closed-form MSM,
+ *     NTT round trip
+ *   - toy circuit: known-answer proof (r = s = 0) recorded in SURVEY.md 8(c) from the
+ *     reference itself, plus the reference's own acceptance criterion (the
+ *     proof verifies under toy_vk.json with public input 2)
+ *
+ * Paths below are relative to /root/reference/rust-rapidsnark/rapidsnark/src/.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "field.h"
+#include "bn254_ref.h"
+
+/* ---------------------------------------------------------------- constants */
+
+/* fq_raw_generic.cpp:6-8, fq_generic.cpp:8 */
+const fparams_t ORA_FQ = {
+    {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    0x87d20782e4866389ULL,
+    {{0xf32cfc5b538afa89ULL, 0xb5e71911d44501fbULL, 0x47ab1eff0a417ff6ULL, 0x06d89f71cab8351fULL}},
+    {{0xb1cd6dafda1530dfULL, 0x62f210e6a7283db6ULL, 0xef7f0b0c0ada0afbULL, 0x20fd6e902d592544ULL}},
+    /* R mod q */
+    {{0xd35d438dc58f0d9dULL, 0x0a78eb28f5c70b3dULL, 0x666ea36f7879462cULL, 0x0e0a77c19a07df2fULL}},
+};
+/* fr_raw_generic.cpp:5-7, fr_generic.cpp:8 */
+const fparams_t ORA_FR = {
+    {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL},
+    0xc2e1f593efffffffULL,
+    {{0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL}},
+    {{0x5e94d8e1b4bf0040ULL, 0x2a489cbe1cfbb6b8ULL, 0x893cc664a19fcfedULL, 0x0cf8594b7fcc657cULL}},
+    /* R mod r */
+    {{0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL}},
+};
+
+#define FQ (&ORA_FQ)
+#define FR (&ORA_FR)
+
+/* ---------------------------------------------------------------- field helpers */
+
+/* fq.cpp:259-278 (square-and-multiply, MSB first) */
+void fe_pow(const fparams_t* F, fe_t* r, const fe_t* base, const u64 e[4])
+{
+    fe_t acc = F->one, b = *base;
+    int  found = 0;
+    for (int i = 255; i >= 0; i--) {
+        int bit = (int)((e[i >> 6] >> (i & 63)) & 1);
+        if (!found) {
+            if (!bit) continue;
+            acc   = b;
+            found = 1;
+            continue;
+        }
+        fe_sqr(F, &acc, &acc);
+        if (bit) fe_mul(F, &acc, &acc, &b);
+    }
+    *r = acc;
+}
+
+/* fq.cpp:238-250 : the reference computes mpz_invert(a_mont) * R^3 (Montgomery),
+ * i.e. the Montgomery form of a^-1.  a^(p-2) in the Montgomery domain is the
+ * same canonical value.  inv(0) = 0 (mpz_invert leaves 0). */
+void fe_inv(const fparams_t* F, fe_t* r, const fe_t* a)
+{
+    u64 e[4];
+    u64 two[4] = {2, 0, 0, 0};
+    raw_sub(e, F->p, two);
+    if (fe_is_zero(a)) {
+        memset(r, 0, sizeof *r);
+        return;
+    }
+    fe_pow(F, r, a, e);
+}
+
+/* fq.cpp:225-236 */
+int fe_to_dec(const fparams_t* F, char* out, const fe_t* a)
+{
+    fe_t s;
+    fe_from_mont(F, &s, a);
+    /* repeated division of the 256-bit value by 10^19 */
+    u64  w[4] = {s.v[0], s.v[1], s.v[2], s.v[3]};
+    char buf[100];
+    int  len = 0;
+    const u64 CH = 10000000000000000000ULL;
+    u64  chunks[6];
+    int  nch = 0;
+    while (w[0] | w[1] | w[2] | w[3]) {
+        u128 rem = 0;
+        for (int i = 3; i >= 0; i--) {
+            u128 cur = (rem << 64) | w[i];
+            w[i]     = (u64)(cur / CH);
+            rem      = cur % CH;
+        }
+        chunks[nch++] = (u64)rem;
+    }
+    if (nch == 0) {
+        out[0] = '0';
+        out[1] = 0;
+        return 1;
+    }
+    len = sprintf(buf, "%llu", (unsigned long long)chunks[nch - 1]);
+    for (int i = nch - 2; i >= 0; i--) len += sprintf(buf + len, "%019llu", (unsigned long long)chunks[i]);
+    memcpy(out, buf, (size_t)len + 1);
+    return len;
+}
+
+/* fq.cpp:183-191 (radix 10 only; value reduced mod p then toMontgomery) */
+void fe_from_dec(const fparams_t* F, fe_t* r, const char* s)
+{
+    /* accumulate in the Montgomery domain: acc = acc*10 + d */
+    fe_t acc, ten, d;
+    memset(&acc, 0, sizeof acc);
+    fe_t t10 = {{10, 0, 0, 0}};
+    fe_to_mont(F, &ten, &t10);
+    for (; *s; s++) {
+        if (*s < '0' || *s > '9') continue;
+        fe_t dv = {{(u64)(*s - '0'), 0, 0, 0}};
+        fe_to_mont(F, &d, &dv);
+        fe_mul(F, &acc, &acc, &ten);
+        fe_add(F, &acc, &acc, &d);
+    }
+    *r = acc;
+}
+
+/* ---------------------------------------------------------------- Fq2 (f2field.cpp) */
+
+typedef struct { fe_t a, b; } fq2_t; /* a + b*u, u^2 = -1 (alt_bn128.hpp:37: f2("-1")) */
+
+static inline int  fq2_is_zero(const fq2_t* x) { return fe_is_zero(&x->a) && fe_is_zero(&x->b); }
+static inline int  fq2_eq(const fq2_t* x, const fq2_t* y) { return fe_eq(&x->a, &y->a) && fe_eq(&x->b, &y->b); }
+static inline void fq2_add(fq2_t* r, const fq2_t* x, const fq2_t* y)
+{
+    fe_add(FQ, &r->a, &x->a, &y->a);
+    fe_add(FQ, &r->b, &x->b, &y->b);
+}
+static inline void fq2_sub(fq2_t* r, const fq2_t* x, const fq2_t* y)
+{
+    fe_sub(FQ, &r->a, &x->a, &y->a);
+    fe_sub(FQ, &r->b, &x->b, &y->b);
+}
+static inline void fq2_neg(fq2_t* r, const fq2_t* x)
+{
+    fe_neg(FQ, &r->a, &x->a);
+    fe_neg(FQ, &r->b, &x->b);
+}
+/* f2field.cpp:122-142 : Karatsuba, non-residue -1 */
+static inline void fq2_mul(fq2_t* r, const fq2_t* x, const fq2_t* y)
+{
+    fe_t aa, bb, bbr, s1, s2, ra, rb;
+    fe_mul(FQ, &aa, &x->a, &y->a);
+    fe_mul(FQ, &bb, &x->b, &y->b);
+    fe_neg(FQ, &bbr, &bb);
+    fe_add(FQ, &s1, &x->a, &x->b);
+    fe_add(FQ, &s2, &y->a, &y->b);
+    fe_add(FQ, &ra, &aa, &bbr);
+    fe_mul(FQ, &rb, &s1, &s2);
+    fe_sub(FQ, &rb, &rb, &aa);
+    fe_sub(FQ, &rb, &rb, &bb);
+    r->a = ra;
+    r->b = rb;
+}
+/* f2field.cpp:144-158 : complex squaring */
+static inline void fq2_sqr(fq2_t* r, const fq2_t* x)
+{
+    fe_t ab, t1, t2, ra;
+    fe_mul(FQ, &ab, &x->a, &x->b);
+    fe_add(FQ, &t1, &x->a, &x->b);
+    fe_sub(FQ, &t2, &x->a, &x->b);
+    fe_mul(FQ, &ra, &t1, &t2);
+    r->a = ra;
+    fe_add(FQ, &r->b, &ab, &ab);
+}
+/* f2field.cpp:178-190 */
+static inline void fq2_inv(fq2_t* r, const fq2_t* x)
+{
+    fe_t t0, t1, t2, t3;
+    fe_sqr(FQ, &t0, &x->a);
+    fe_sqr(FQ, &t1, &x->b);
+    fe_neg(FQ, &t2, &t1);
+    fe_sub(FQ, &t2, &t0, &t2);
+    fe_inv(FQ, &t3, &t2);
+    fe_mul(FQ, &r->a, &x->a, &t3);
+    fe_mul(FQ, &r->b, &x->b, &t3);
+    fe_neg(FQ, &r->b, &r->b);
+}
+static inline void fq2_one(fq2_t* r)
+{
+    r->a = ORA_FQ.one;
+    memset(&r->b, 0, sizeof r->b);
+}
+
+/* ---------------------------------------------------------------- curve instantiations */
+
+#define CV(n) g1_##n
+#define FE fe_t
+#define F_MUL(r, a, b) fe_mul(FQ, r, a, b)
+#define F_SQR(r, a) fe_sqr(FQ, r, a)
+#define F_ADD(r, a, b) fe_add(FQ, r, a, b)
+#define F_SUB(r, a, b) fe_sub(FQ, r, a, b)
+#define F_NEG(r, a) fe_neg(FQ, r, a)
+#define F_ISZERO(a) fe_is_zero(a)
+#define F_EQ(a, b) fe_eq(a, b)
+#define F_ONE(r) (*(r) = ORA_FQ.one)
+#define F_ZERO(r) memset((r), 0, sizeof(fe_t))
+#define F_INV(r, a) fe_inv(FQ, r, a)
+#include "curve_tmpl.h"
+#undef CV
+#undef FE
+#undef F_MUL
+#undef F_SQR
+#undef F_ADD
+#undef F_SUB
+#undef F_NEG
+#undef F_ISZERO
+#undef F_EQ
+#undef F_ONE
+#undef F_ZERO
+#undef F_INV
+
+#define CV(n) g2_##n
+#define FE fq2_t
+#define F_MUL(r, a, b) fq2_mul(r, a, b)
+#define F_SQR(r, a) fq2_sqr(r, a)
+#define F_ADD(r, a, b) fq2_add(r, a, b)
+#define F_SUB(r, a, b) fq2_sub(r, a, b)
+#define F_NEG(r, a) fq2_neg(r, a)
+#define F_ISZERO(a) fq2_is_zero(a)
+#define F_EQ(a, b) fq2_eq(a, b)
+#define F_ONE(r) fq2_one(r)
+#define F_ZERO(r) memset((r), 0, sizeof(fq2_t))
+#define F_INV(r, a) fq2_inv(r, a)
+#include "curve_tmpl.h"
+#undef CV
+#undef FE
+
+/* ---------------------------------------------------------------- NTT (fft.cpp) */
+
+typedef struct {
+    unsigned s;        /* log2 of table size */
+    fe_t*    roots;    /* roots[i] = g^i, Montgomery, g primitive 2^s-th root */
+    fe_t     pow2inv[32];
+} ntt_t;
+
+static unsigned ilog2(u64 n)
+{
+    unsigned r = 0;
+    while (n > 1) {
+        n >>= 1;
+        r++;
+    }
+    return r;
+}
+
+/* fft.cpp:40-136.  nqr search (fft.cpp:60-67) finds 5 for BN254 r; it is
+ * recomputed here the same way (smallest v >= 2 with v^((r-1)/2) != 1). */
+static int ntt_init(ntt_t* t, u64 max_domain)
+{
+    unsigned dp = ilog2(max_domain);
+    u64      qm1d2[4], one[4] = {1, 0, 0, 0}, e[4];
+    raw_sub(qm1d2, ORA_FR.p, one);
+    for (int j = 0; j < 4; j++) qm1d2[j] = (qm1d2[j] >> 1) | (j < 3 ? qm1d2[j + 1] << 63 : 0);
+    u64  nq = 2;
+    fe_t nqr, aux;
+    for (;; nq++) {
+        fe_t v = {{nq, 0, 0, 0}};
+        fe_to_mont(FR, &nqr, &v);
+        fe_pow(FR, &aux, &nqr, qm1d2);
+        if (!fe_eq(&aux, &ORA_FR.one)) break;
+    }
+    unsigned s = 1;
+    memcpy(e, qm1d2, 32);
+    while (!(e[0] & 1) && s < dp) {
+        for (int j = 0; j < 4; j++) e[j] = (e[j] >> 1) | (j < 3 ? e[j + 1] << 63 : 0);
+        s++;
+    }
+    if (s < dp) return -1; /* "Domain size too big for the curve" */
+    t->s     = s;
+    u64 nr   = (u64)1 << s;
+    t->roots = (fe_t*)malloc(nr * sizeof(fe_t));
+    if (!t->roots) return -2;
+    t->roots[0]   = ORA_FR.one;
+    t->pow2inv[0] = ORA_FR.one;
+    if (nr > 1) {
+        fe_pow(FR, &t->roots[1], &nqr, e);
+        fe_t two = {{2, 0, 0, 0}}, twom;
+        fe_to_mont(FR, &twom, &two);
+        fe_inv(FR, &t->pow2inv[1], &twom);
+    }
+    for (u64 i = 2; i < nr; i++) fe_mul(FR, &t->roots[i], &t->roots[i - 1], &t->roots[1]);
+    for (unsigned i = 2; i <= s && i < 32; i++) fe_mul(FR, &t->pow2inv[i], &t->pow2inv[i - 1], &t->pow2inv[1]);
+    return 0;
+}
+static void ntt_free(ntt_t* t)
+{
+    free(t->roots);
+    t->roots = NULL;
+}
+static inline const fe_t* ntt_root(const ntt_t* t, unsigned domain_pow, u64 idx)
+{
+    return &t->roots[idx << (t->s - domain_pow)]; /* fft.hpp:40-43 */
+}
+static inline u64 bitrev(u64 x, unsigned bits)
+{
+    u64 r = 0;
+    for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+/* fft.cpp:170-219 : bit-reverse, then in-place DIT stages */
+static void ntt_fwd(const ntt_t* t, fe_t* a, u64 n)
+{
+    unsigned dp = ilog2(n);
+    for (u64 i = 0; i < n; i++) {
+        u64 r = bitrev(i, dp);
+        if (i > r) {
+            fe_t tmp = a[i];
+            a[i]     = a[r];
+            a[r]     = tmp;
+        }
+    }
+    for (unsigned s = 1; s <= dp; s++) {
+        u64 m = (u64)1 << s, md2 = m >> 1;
+        for (u64 i = 0; i < (n >> 1); i++) {
+            u64  k = (i / md2) * m, j = i % md2;
+            fe_t tt, u;
+            fe_mul(FR, &tt, ntt_root(t, s, j), &a[k + j + md2]);
+            u = a[k + j];
+            fe_add(FR, &a[k + j], &tt, &u);
+            fe_sub(FR, &a[k + j + md2], &u, &tt);
+        }
+    }
+}
+/* fft.cpp:222-246 */
+static void ntt_inv(const ntt_t* t, fe_t* a, u64 n)
+{
+    ntt_fwd(t, a, n);
+    unsigned    dp  = ilog2(n);
+    u64         nd2 = n >> 1;
+    const fe_t* sc  = &t->pow2inv[dp];
+    for (u64 i = 1; i < nd2; i++) {
+        u64  r   = n - i;
+        fe_t tmp = a[i];
+        fe_mul(FR, &a[i], &a[r], sc);
+        fe_mul(FR, &a[r], &tmp, sc);
+    }
+    fe_mul(FR, &a[0], &a[0], sc);
+    if (n > 1) fe_mul(FR, &a[nd2], &a[nd2], sc);
+}
+
+/* ---------------------------------------------------------------- iden3 binfile (binfile_utils.cpp:13-58) */
+
+typedef struct {
+    uint8_t* base;
+    size_t   size;
+    int      fd;
+    struct { const uint8_t* p; u64 size; } sec[16];
+} binfile_t;
+
+static int binfile_open(binfile_t* bf, const char* path, const char* type, uint32_t max_version)
+{
+    memset(bf, 0, sizeof *bf);
+    bf->fd = open(path, O_RDONLY);
+    if (bf->fd < 0) return ORA_ERR_IO;
+    struct stat sb;
+    if (fstat(bf->fd, &sb) < 0) {
+        close(bf->fd);
+        return ORA_ERR_IO;
+    }
+    bf->size = (size_t)sb.st_size;
+    bf->base = (uint8_t*)mmap(NULL, bf->size, PROT_READ, MAP_PRIVATE, bf->fd, 0);
+    if (bf->base == MAP_FAILED) {
+        close(bf->fd);
+        return ORA_ERR_IO;
+    }
+    int rc = ORA_ERR_FORMAT;
+    if (bf->size < 12 || memcmp(bf->base, type, 4) != 0) goto fail;
+    uint32_t version, nsec;
+    memcpy(&version, bf->base + 4, 4);
+    memcpy(&nsec, bf->base + 8, 4);
+    if (version > max_version) goto fail;
+    size_t pos = 12;
+    for (uint32_t i = 0; i < nsec; i++) {
+        if (pos + 12 > bf->size) goto fail;
+        uint32_t st;
+        u64      ss;
+        memcpy(&st, bf->base + pos, 4);
+        memcpy(&ss, bf->base + pos + 4, 8);
+        pos += 12;
+        if (ss > bf->size - pos) goto fail;
+        if (st < 16 && bf->sec[st].p == NULL) { /* first occurrence = sectionPos 0 */
+            bf->sec[st].p    = bf->base + pos;
+            bf->sec[st].size = ss;
+        }
+        pos += ss;
+    }
+    return 0;
+fail:
+    munmap(bf->base, bf->size);
+    close(bf->fd);
+    return rc;
+}
+static void binfile_close(binfile_t* bf)
+{
+    if (bf->base) munmap(bf->base, bf->size);
+    if (bf->fd >= 0) close(bf->fd);
+    bf->base = NULL;
+}
+
+/* ---------------------------------------------------------------- Groth16 prove (groth16.cpp:41-360) */
+
+#pragma pack(push, 1)
+typedef struct { uint32_t m, c, s; fe_t coef; } coef_t; /* groth16.hpp:33-42 */
+#pragma pack(pop)
+
+typedef struct {
+    uint32_t         n_vars, n_public, domain_size;
+    u64              n_coefs;
+    const g1_aff_t * alpha1, *beta1, *delta1;
+    const g2_aff_t * beta2, *delta2;
+    const coef_t*    coefs;
+    const g1_aff_t * pA, *pB1, *pC, *pH;
+    const g2_aff_t*  pB2;
+} zkey_view_t;
+
+/* zkey_utils.hpp:49-87 + fullprover.cpp:150-174 */
+static int zkey_view(zkey_view_t* z, const binfile_t* bf)
+{
+    static const uint8_t R_LE[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9,
+                                     0x79, 0x48, 0xe8, 0x33, 0x28, 0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45,
+                                     0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+    for (int s = 1; s <= 9; s++) {
+        if (s == 3) continue;
+        if (!bf->sec[s].p) return ORA_ERR_FORMAT;
+    }
+    uint32_t proto;
+    if (bf->sec[1].size < 4) return ORA_ERR_FORMAT;
+    memcpy(&proto, bf->sec[1].p, 4);
+    if (proto != 1) return ORA_ERR_FORMAT;
+    const uint8_t* h = bf->sec[2].p;
+    uint32_t       n8q, n8r;
+    memcpy(&n8q, h, 4);
+    if (n8q != 32) return ORA_ERR_CURVE;
+    h += 4 + n8q;
+    memcpy(&n8r, h, 4);
+    if (n8r != 32) return ORA_ERR_CURVE;
+    if (memcmp(h + 4, R_LE, 32) != 0) return ORA_ERR_CURVE;
+    h += 4 + n8r;
+    memcpy(&z->n_vars, h, 4);
+    memcpy(&z->n_public, h + 4, 4);
+    memcpy(&z->domain_size, h + 8, 4);
+    h += 12;
+    z->alpha1 = (const g1_aff_t*)h;
+    h += 64;
+    z->beta1 = (const g1_aff_t*)h;
+    h += 64;
+    z->beta2 = (const g2_aff_t*)h;
+    h += 128;
+    h += 128; /* gamma2 unused */
+    z->delta1 = (const g1_aff_t*)h;
+    h += 64;
+    z->delta2  = (const g2_aff_t*)h;
+    z->n_coefs = bf->sec[4].size / (12 + n8r);                 /* zkey_utils.hpp:84 */
+    z->coefs   = (const coef_t*)(bf->sec[4].p + 4);            /* groth16.cpp:33 */
+    z->pA      = (const g1_aff_t*)bf->sec[5].p;
+    z->pB1     = (const g1_aff_t*)bf->sec[6].p;
+    z->pB2     = (const g2_aff_t*)bf->sec[7].p;
+    z->pC      = (const g1_aff_t*)bf->sec[8].p;
+    z->pH      = (const g1_aff_t*)bf->sec[9].p;
+    return 0;
+}
+
+typedef struct { g1_aff_t A; g2_aff_t B; g1_aff_t C; } proof_t;
+
+/* groth16.cpp:378-410 + nlohmann dump(): keys sorted, no whitespace */
+static int proof_to_json(const proof_t* p, char* out, size_t cap)
+{
+    char ax[80], ay[80], bxa[80], bxb[80], bya[80], byb[80], cx[80], cy[80];
+    fe_to_dec(FQ, ax, &p->A.x);
+    fe_to_dec(FQ, ay, &p->A.y);
+    fe_to_dec(FQ, bxa, &p->B.x.a);
+    fe_to_dec(FQ, bxb, &p->B.x.b);
+    fe_to_dec(FQ, bya, &p->B.y.a);
+    fe_to_dec(FQ, byb, &p->B.y.b);
+    fe_to_dec(FQ, cx, &p->C.x);
+    fe_to_dec(FQ, cy, &p->C.y);
+    int n = snprintf(out, cap,
+                     "{\"pi_a\":[\"%s\",\"%s\",\"1\"],\"pi_b\":[[\"%s\",\"%s\"],[\"%s\",\"%s\"],[\"1\",\"0\"]],"
+                     "\"pi_c\":[\"%s\",\"%s\",\"1\"],\"protocol\":\"groth16\"}",
+                     ax, ay, bxa, bxb, bya, byb, cx, cy);
+    return (n < 0 || (size_t)n >= cap) ? ORA_ERR_BUFFER : n;
+}
+
+static int groth16_prove(const zkey_view_t* z, const fe_t* wtns, const uint8_t r_std[32], const uint8_t s_std[32],
+                         proof_t* out, int nthreads, fe_t* h_scalars_out)
+{
+    const u64 N  = z->domain_size;
+    const u64 sW = 32;
+    g1_pt_t   pi_a, pib1, pi_c, pih, p1;
+    g2_pt_t   pi_b, p2;
+
+    /* groth16.cpp:88-112 */
+    g1_msm(&pi_a, z->pA, (const uint8_t*)wtns, sW, z->n_vars, nthreads);
+    g1_msm(&pib1, z->pB1, (const uint8_t*)wtns, sW, z->n_vars, nthreads);
+    g2_msm(&pi_b, z->pB2, (const uint8_t*)wtns, sW, z->n_vars, nthreads);
+    g1_msm(&pi_c, z->pC, (const uint8_t*)(wtns + (z->n_public + 1)), sW, (u64)z->n_vars - z->n_public - 1, nthreads);
+
+    fe_t* a = (fe_t*)calloc(N, sizeof(fe_t));
+    fe_t* b = (fe_t*)calloc(N, sizeof(fe_t));
+    fe_t* c = (fe_t*)calloc(N, sizeof(fe_t));
+    if (!a || !b || !c) return ORA_ERR_IO;
+
+    /* groth16.cpp:137-156 : ab[c] += wtns[s] (x) coef  (coef stored *R^2 => Montgomery) */
+    for (u64 i = 0; i < z->n_coefs; i++) {
+        coef_t cf;
+        memcpy(&cf, &z->coefs[i], sizeof cf);
+        fe_t* ab = (cf.m == 0) ? a : b;
+        fe_t  aux;
+        fe_mul(FR, &aux, &wtns[cf.s], &cf.coef);
+        fe_add(FR, &ab[cf.c], &ab[cf.c], &aux);
+    }
+    /* groth16.cpp:160-167 */
+    for (u64 i = 0; i < N; i++) fe_mul(FR, &c[i], &a[i], &b[i]);
+
+    ntt_t ntt;
+    int   rc = ntt_init(&ntt, 2 * N); /* groth16.hpp:96 */
+    if (rc) return ORA_ERR_FORMAT;
+    unsigned dp = ilog2(N);
+    /* groth16.cpp:172-262 */
+    fe_t* vec[3] = {a, b, c};
+    for (int k = 0; k < 3; k++) {
+        fe_t* x = vec[k];
+        ntt_inv(&ntt, x, N);
+        for (u64 i = 0; i < N; i++) fe_mul(FR, &x[i], &x[i], ntt_root(&ntt, dp + 1, i));
+        ntt_fwd(&ntt, x, N);
+    }
+    /* groth16.cpp:266-275 */
+    for (u64 i = 0; i < N; i++) {
+        fe_mul(FR, &a[i], &a[i], &b[i]);
+        fe_sub(FR, &a[i], &a[i], &c[i]);
+        fe_from_mont(FR, &a[i], &a[i]);
+    }
+    if (h_scalars_out) memcpy(h_scalars_out, a, N * sizeof(fe_t));
+    /* groth16.cpp:281-283 */
+    g1_msm(&pih, z->pH, (const uint8_t*)a, sW, N, nthreads);
+    ntt_free(&ntt);
+    free(b);
+    free(c);
+    free(a);
+
+    /* groth16.cpp:328-352 ; r, s are standard-form integers < r (injected) */
+    g1_madd(&pi_a, &pi_a, z->alpha1);
+    g1_mul_scalar_aff(&p1, z->delta1, r_std, 32);
+    g1_add(&pi_a, &pi_a, &p1);
+
+    g2_madd(&pi_b, &pi_b, z->beta2);
+    g2_mul_scalar_aff(&p2, z->delta2, s_std, 32);
+    g2_add(&pi_b, &pi_b, &p2);
+
+    g1_madd(&pib1, &pib1, z->beta1);
+    g1_mul_scalar_aff(&p1, z->delta1, s_std, 32);
+    g1_add(&pib1, &pib1, &p1);
+
+    g1_add(&pi_c, &pi_c, &pih);
+    g1_mul_scalar(&p1, &pi_a, s_std, 32);
+    g1_add(&pi_c, &pi_c, &p1);
+    g1_mul_scalar(&p1, &pib1, r_std, 32);
+    g1_add(&pi_c, &pi_c, &p1);
+
+    fe_t rr, ss, rs;
+    memcpy(&rr, r_std, 32);
+    memcpy(&ss, s_std, 32);
+    fe_mul(FR, &rs, &rr, &ss);
+    fe_to_mont(FR, &rs, &rs); /* = r*s mod r, standard form (groth16.cpp:348-349) */
+    g1_mul_scalar_aff(&p1, z->delta1, (const uint8_t*)&rs, 32);
+    g1_sub(&pi_c, &pi_c, &p1);
+
+    g1_to_aff(&out->A, &pi_a);
+    g2_to_aff(&out->B, &pi_b);
+    g1_to_aff(&out->C, &pi_c);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- exported C API (ctypes) */
+
+void ora_field_op(int field, int op, const u64* a, const u64* b, u64* r)
+{
+    const fparams_t* F = field ? FR : FQ;
+    fe_t             x, y, z;
+    memcpy(&x, a, 32);
+    if (b) memcpy(&y, b, 32);
+    switch (op) {
+    case ORA_OP_ADD: fe_add(F, &z, &x, &y); break;
+    case ORA_OP_SUB: fe_sub(F, &z, &x, &y); break;
+    case ORA_OP_NEG: fe_neg(F, &z, &x); break;
+    case ORA_OP_MUL: fe_mul(F, &z, &x, &y); break;
+    case ORA_OP_SQR: fe_sqr(F, &z, &x); break;
+    case ORA_OP_TOMONT: fe_to_mont(F, &z, &x); break;
+    case ORA_OP_FROMMONT: fe_from_mont(F, &z, &x); break;
+    case ORA_OP_INV: fe_inv(F, &z, &x); break;
+    default: memset(&z, 0, sizeof z);
+    }
+    memcpy(r, &z, 32);
+}
+/* vector form: n elements each */
+void ora_field_op_vec(int field, int op, const u64* a, const u64* b, u64* r, u64 n)
+{
+    for (u64 i = 0; i < n; i++) ora_field_op(field, op, a + 4 * i, b ? b + 4 * i : NULL, r + 4 * i);
+}
+int  ora_fe_to_dec(int field, const u64* a, char* out) { return fe_to_dec(field ? FR : FQ, out, (const fe_t*)a); }
+void ora_fe_from_dec(int field, const char* s, u64* r) { fe_from_dec(field ? FR : FQ, (fe_t*)r, s); }
+
+void ora_fq2_op(int op, const u64* a, const u64* b, u64* r)
+{
+    fq2_t x, y, z;
+    memcpy(&x, a, 64);
+    if (b) memcpy(&y, b, 64);
+    switch (op) {
+    case ORA_OP_ADD: fq2_add(&z, &x, &y); break;
+    case ORA_OP_SUB: fq2_sub(&z, &x, &y); break;
+    case ORA_OP_NEG: fq2_neg(&z, &x); break;
+    case ORA_OP_MUL: fq2_mul(&z, &x, &y); break;
+    case ORA_OP_SQR: fq2_sqr(&z, &x); break;
+    case ORA_OP_INV: fq2_inv(&z, &x); break;
+    default: memset(&z, 0, sizeof z);
+    }
+    memcpy(r, &z, 64);
+}
+
+/* XYZZ primitives, G1 (group=0: 4-limb coords) or G2 (group=1: 8-limb coords) */
+void ora_pt_op(int group, int op, const void* p1, const void* p2, void* r)
+{
+    if (group == 0) {
+        g1_pt_t a, out;
+        memcpy(&a, p1, sizeof a);
+        switch (op) {
+        case ORA_PT_ADD: { g1_pt_t b; memcpy(&b, p2, sizeof b); g1_add(&out, &a, &b); break; }
+        case ORA_PT_MADD: { g1_aff_t b; memcpy(&b, p2, sizeof b); g1_madd(&out, &a, &b); break; }
+        case ORA_PT_DBL: g1_dbl(&out, &a); break;
+        case ORA_PT_NEG: g1_neg(&out, &a); break;
+        default: g1_set_zero(&out);
+        }
+        memcpy(r, &out, sizeof out);
+    } else {
+        g2_pt_t a, out;
+        memcpy(&a, p1, sizeof a);
+        switch (op) {
+        case ORA_PT_ADD: { g2_pt_t b; memcpy(&b, p2, sizeof b); g2_add(&out, &a, &b); break; }
+        case ORA_PT_MADD: { g2_aff_t b; memcpy(&b, p2, sizeof b); g2_madd(&out, &a, &b); break; }
+        case ORA_PT_DBL: g2_dbl(&out, &a); break;
+        case ORA_PT_NEG: g2_neg(&out, &a); break;
+        default: g2_set_zero(&out);
+        }
+        memcpy(r, &out, sizeof out);
+    }
+}
+void ora_pt_to_affine(int group, const void* p, void* out_aff)
+{
+    if (group == 0) {
+        g1_pt_t a;
+        memcpy(&a, p, sizeof a);
+        g1_to_aff((g1_aff_t*)out_aff, &a);
+    } else {
+        g2_pt_t a;
+        memcpy(&a, p, sizeof a);
+        g2_to_aff((g2_aff_t*)out_aff, &a);
+    }
+}
+int ora_pt_eq(int group, const void* p1, const void* p2)
+{
+    if (group == 0) return g1_eq((const g1_pt_t*)p1, (const g1_pt_t*)p2);
+    return g2_eq((const g2_pt_t*)p1, (const g2_pt_t*)p2);
+}
+/* generators, Montgomery affine (alt_bn128.hpp:41-54) */
+void ora_generator(int group, void* out_aff)
+{
+    if (group == 0) {
+        g1_aff_t g;
+        fe_from_dec(FQ, &g.x, "1");
+        fe_from_dec(FQ, &g.y, "2");
+        memcpy(out_aff, &g, sizeof g);
+    } else {
+        g2_aff_t g;
+        fe_from_dec(FQ, &g.x.a, "10857046999023057135944570762232829481370756359578518086990519993285655852781");
+        fe_from_dec(FQ, &g.x.b, "11559732032986387107991004021392285783925812861821192530917403151452391805634");
+        fe_from_dec(FQ, &g.y.a, "8495653923123431417604973247489272438418190587263600148770280649306958101930");
+        fe_from_dec(FQ, &g.y.b, "4082367875863433681332203403145435568316851327593401208105741076214120093531");
+        memcpy(out_aff, &g, sizeof g);
+    }
+}
+/* out (XYZZ) = scalar * base_aff ; Curve::mulByScalar (curve.hpp:195-207) */
+void ora_mul_scalar(int group, const void* base_aff, const uint8_t* scalar, unsigned scalar_size, void* out_xyzz)
+{
+    if (group == 0)
+        g1_mul_scalar_aff((g1_pt_t*)out_xyzz, (const g1_aff_t*)base_aff, scalar, scalar_size);
+    else
+        g2_mul_scalar_aff((g2_pt_t*)out_xyzz, (const g2_aff_t*)base_aff, scalar, scalar_size);
+}
+/* bases[i] = (start+i+1)*G as Montgomery affine; deterministic synthetic point table.
+ * Built with mixed adds then converted to affine (one inversion per point is too
+ * slow at 2^20, so Montgomery's batch-inversion trick is used). */
+void ora_gen_points(int group, u64 start, u64 n, void* out_aff)
+{
+    if (n == 0) return;
+    if (group == 0) {
+        g1_aff_t  g;
+        ora_generator(0, &g);
+        g1_pt_t*  pts = (g1_pt_t*)malloc(n * sizeof(g1_pt_t));
+        uint8_t   sc[32] = {0};
+        u64       k = start + 1;
+        memcpy(sc, &k, 8);
+        g1_mul_scalar_aff(&pts[0], &g, sc, 32);
+        for (u64 i = 1; i < n; i++) g1_madd(&pts[i], &pts[i - 1], &g);
+        /* batch inversion of zz*zzz-free form: x = X/ZZ, y = Y/ZZZ; invert ZZZ, derive ZZ^-1 = ZZZ^-1 * Z where Z = ZZZ/ZZ */
+        fe_t* pref = (fe_t*)malloc(n * sizeof(fe_t));
+        fe_t  acc  = ORA_FQ.one;
+        for (u64 i = 0; i < n; i++) {
+            pref[i] = acc;
+            if (!g1_is_zero(&pts[i])) fe_mul(FQ, &acc, &acc, &pts[i].zzz);
+        }
+        fe_t inv;
+        fe_inv(FQ, &inv, &acc);
+        g1_aff_t* out = (g1_aff_t*)out_aff;
+        for (u64 i = n; i-- > 0;) {
+            if (g1_is_zero(&pts[i])) {
+                memset(&out[i], 0, sizeof out[i]);
+                continue;
+            }
+            fe_t zzz_inv, zz_inv, z;
+            fe_mul(FQ, &zzz_inv, &inv, &pref[i]);
+            fe_mul(FQ, &inv, &inv, &pts[i].zzz);
+            /* Z = ZZZ / ZZ => ZZ^-1 = Z^... : ZZ^-1 = ZZZ^-1 * (ZZZ/ZZ) ; ZZZ/ZZ = Z ; Z = ZZZ * ZZ^-1 (circular) ->
+             * use ZZ^-1 = (ZZZ^-1)^2 * ZZ^2 : since ZZ^3 = ZZZ^2, ZZ^-1 = ZZ^2 / ZZZ^2 */
+            fe_sqr(FQ, &z, &zzz_inv);
+            fe_sqr(FQ, &zz_inv, &pts[i].zz);
+            fe_mul(FQ, &zz_inv, &zz_inv, &z);
+            fe_mul(FQ, &out[i].x, &pts[i].x, &zz_inv);
+            fe_mul(FQ, &out[i].y, &pts[i].y, &zzz_inv);
+        }
+        free(pref);
+        free(pts);
+    } else {
+        g2_aff_t g;
+        ora_generator(1, &g);
+        g2_pt_t  cur;
+        uint8_t  sc[32] = {0};
+        u64      k = start + 1;
+        memcpy(sc, &k, 8);
+        g2_mul_scalar_aff(&cur, &g, sc, 32);
+        g2_pt_t* pts = (g2_pt_t*)malloc(n * sizeof(g2_pt_t));
+        pts[0]       = cur;
+        for (u64 i = 1; i < n; i++) g2_madd(&pts[i], &pts[i - 1], &g);
+        fq2_t* pref = (fq2_t*)malloc(n * sizeof(fq2_t));
+        fq2_t  acc;
+        fq2_one(&acc);
+        for (u64 i = 0; i < n; i++) {
+            pref[i] = acc;
+            if (!g2_is_zero(&pts[i])) fq2_mul(&acc, &acc, &pts[i].zzz);
+        }
+        fq2_t inv;
+        fq2_inv(&inv, &acc);
+        g2_aff_t* out = (g2_aff_t*)out_aff;
+        for (u64 i = n; i-- > 0;) {
+            if (g2_is_zero(&pts[i])) {
+                memset(&out[i], 0, sizeof out[i]);
+                continue;
+            }
+            fq2_t zzz_inv, zz_inv, z;
+            fq2_mul(&zzz_inv, &inv, &pref[i]);
+            fq2_mul(&inv, &inv, &pts[i].zzz);
+            fq2_sqr(&z, &zzz_inv);
+            fq2_sqr(&zz_inv, &pts[i].zz);
+            fq2_mul(&zz_inv, &zz_inv, &z);
+            fq2_mul(&out[i].x, &pts[i].x, &zz_inv);
+            fq2_mul(&out[i].y, &pts[i].y, &zzz_inv);
+        }
+        free(pref);
+        free(pts);
+    }
+}
+
+/* Curve::multiMulByScalar (curve.hpp:209-215).  Result as XYZZ and as affine. */
+void ora_msm(int group, const void* bases_aff, const uint8_t* scalars, u64 scalar_size, u64 n, int nthreads,
+             void* out_xyzz, void* out_aff)
+{
+    if (group == 0) {
+        g1_pt_t r;
+        g1_msm(&r, (const g1_aff_t*)bases_aff, scalars, scalar_size, n, nthreads);
+        if (out_xyzz) memcpy(out_xyzz, &r, sizeof r);
+        if (out_aff) g1_to_aff((g1_aff_t*)out_aff, &r);
+    } else {
+        g2_pt_t r;
+        g2_msm(&r, (const g2_aff_t*)bases_aff, scalars, scalar_size, n, nthreads);
+        if (out_xyzz) memcpy(out_xyzz, &r, sizeof r);
+        if (out_aff) g2_to_aff((g2_aff_t*)out_aff, &r);
+    }
+}
+
+/* FFT<Fr>(max_domain).fft / .ifft on n Montgomery elements in place */
+int ora_ntt(u64* a, u64 n, u64 max_domain, int inverse)
+{
+    ntt_t t;
+    int   rc = ntt_init(&t, max_domain);
+    if (rc) return rc;
+    if (inverse)
+        ntt_inv(&t, (fe_t*)a, n);
+    else
+        ntt_fwd(&t, (fe_t*)a, n);
+    ntt_free(&t);
+    return 0;
+}
+/* roots[idx << (S - domain_pow)] for the table of size max_domain (fft.hpp:40-43) */
+int ora_ntt_root(u64 max_domain, unsigned domain_pow, u64 idx, u64* out)
+{
+    ntt_t t;
+    int   rc = ntt_init(&t, max_domain);
+    if (rc) return rc;
+    memcpy(out, ntt_root(&t, domain_pow, idx), 32);
+    ntt_free(&t);
+    return 0;
+}
+
+int ora_zkey_info(const char* zkey_path, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain_size, u64* n_coefs)
+{
+    binfile_t bf;
+    int       rc = binfile_open(&bf, zkey_path, "zkey", 1);
+    if (rc) return rc;
+    zkey_view_t z;
+    rc = zkey_view(&z, &bf);
+    if (!rc) {
+        *n_vars      = z.n_vars;
+        *n_public    = z.n_public;
+        *domain_size = z.domain_size;
+        *n_coefs     = z.n_coefs;
+    }
+    binfile_close(&bf);
+    return rc;
+}
+
+/* FullProver(zkey).prove(wtns) with injected blinding scalars (standard form, < r).
+ * Writes the compact JSON; optionally the H scalars (domain_size x 32 B, standard form). */
+int ora_prove_files(const char* zkey_path, const char* wtns_path, const uint8_t r_std[32], const uint8_t s_std[32],
+                    int nthreads, char* out_json, size_t cap, u64* h_scalars_out)
+{
+    binfile_t zk, wt;
+    int       rc = binfile_open(&zk, zkey_path, "zkey", 1);
+    if (rc) return rc;
+    zkey_view_t z;
+    rc = zkey_view(&z, &zk);
+    if (rc) {
+        binfile_close(&zk);
+        return rc;
+    }
+    rc = binfile_open(&wt, wtns_path, "wtns", 2);
+    if (rc) {
+        binfile_close(&zk);
+        return rc;
+    }
+    /* wtns_utils.hpp:32-40 + fullprover.cpp:216-221 */
+    static const uint8_t R_LE[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9,
+                                     0x79, 0x48, 0xe8, 0x33, 0x28, 0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45,
+                                     0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+    uint32_t n8 = 0;
+    if (!wt.sec[1].p || !wt.sec[2].p || wt.sec[1].size < 40) rc = ORA_ERR_FORMAT;
+    if (!rc) {
+        memcpy(&n8, wt.sec[1].p, 4);
+        if (n8 != 32 || memcmp(wt.sec[1].p + 4, R_LE, 32) != 0) rc = ORA_ERR_CURVE;
+    }
+    if (!rc && wt.sec[2].size < (u64)z.n_vars * 32) rc = ORA_ERR_FORMAT;
+    if (!rc) {
+        proof_t pf;
+        /* section data may be unaligned for fe_t loads on the mmap: copy */
+        fe_t* w = (fe_t*)malloc((size_t)z.n_vars * 32);
+        memcpy(w, wt.sec[2].p, (size_t)z.n_vars * 32);
+        rc = groth16_prove(&z, w, r_std, s_std, &pf, nthreads, (fe_t*)h_scalars_out);
+        free(w);
+        if (!rc) rc = proof_to_json(&pf, out_json, cap);
+    }
+    binfile_close(&wt);
+    binfile_close(&zk);
+    return rc;
+}
