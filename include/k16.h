@@ -1,0 +1,130 @@
+/*
+ * k16.h -- C ABI of libk16.so: the MI355X (gfx950) device shim under the Groth16 prover.
+ *
+ * This is the "thin extern-C shim" between the C++ prover host code and the HIP kernels.
+ * Plain pointers and sizes only; every function returns an int status (K16_OK = 0), never
+ * throws, and never falls back to a CPU implementation: without a usable HIP device the
+ * context cannot be created and every entry point fails with K16_ERR_NO_DEVICE.
+ *
+ * What each entry point replaces in the reference (paths relative to
+ * rust-rapidsnark/rapidsnark/src/ of aptos-labs/keyless-zk-proofs):
+ *
+ *   k16_msm*            Curve<F>::multiMulByScalar -> ParallelMultiexp::multiexp
+ *                       (curve.hpp:209-215, multiexp.cpp:183-245), G1 and G2
+ *   k16_ntt             FFT<RawFr>::fft / ::ifft (fft.cpp:192-246)
+ *   k16_prover_*        Groth16::makeProver / Prover::prove (groth16.cpp:18-39, 41-360) and the
+ *                       FullProverImpl ctor / prove around them (fullprover.cpp:136-250)
+ *   k16_field_op_vec,
+ *   k16_point_op_vec    RawFq/RawFr raw ops and Curve<F>::add/dbl (fq_raw_generic.cpp:12-233,
+ *                       curve.cpp:91-458) exposed as batch kernels for parity tests
+ *
+ * Data formats are the reference's own: field elements are 32 bytes,
+ * little-endian; Fq/Fr values in Montgomery form (R = 2^256) unless stated; G1 affine = x|y
+ * (64 B), G2 affine = x.a|x.b|y.a|y.b (128 B), affine infinity = all zero; XYZZ = x|y|zz|zzz
+ * (128 B / 256 B), infinity <=> zz == 0; MSM scalars = 32 B standard (non-Montgomery) form.
+ */
+#ifndef K16_H
+#define K16_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    K16_OK             = 0,
+    K16_ERR_NO_DEVICE  = -1, /* no HIP device / runtime failure at context creation */
+    K16_ERR_HIP        = -2, /* a HIP call or kernel failed; see k16_last_error */
+    K16_ERR_ARG        = -3,
+    K16_ERR_IO         = -4, /* file open / mmap failure         (-> ZKEY_FILE_LOAD_ERROR) */
+    K16_ERR_FORMAT     = -5, /* malformed zkey / wtns            (-> INVALID_INPUT) */
+    K16_ERR_CURVE      = -6, /* prime is not BN254 r             (-> UNSUPPORTED_ZKEY_CURVE /
+                                                                     WITNESS_GENERATION_INVALID_CURVE) */
+    K16_ERR_BUFFER     = -7
+};
+
+enum { K16_G1 = 0, K16_G2 = 1 };
+enum { K16_FQ = 0, K16_FR = 1 };
+enum { K16_OP_ADD = 0, K16_OP_SUB, K16_OP_NEG, K16_OP_MUL, K16_OP_SQR, K16_OP_TOMONT, K16_OP_FROMMONT };
+enum { K16_PT_ADD = 0, K16_PT_MADD, K16_PT_DBL };
+
+typedef struct k16_ctx    k16_ctx;
+typedef struct k16_prover k16_prover;
+
+/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
+int         k16_ctx_create(int device, k16_ctx** out);
+void        k16_ctx_destroy(k16_ctx* ctx);
+const char* k16_last_error(const k16_ctx* ctx);
+int         k16_sync(k16_ctx* ctx);
+/* the HIP stream every kernel of this context is launched on (hipStream_t as void*) */
+void*       k16_stream(k16_ctx* ctx);
+
+/* ---- device memory (so callers need no HIP of their own) ---- */
+int k16_dev_alloc(k16_ctx* ctx, size_t bytes, void** dptr);
+int k16_dev_free(k16_ctx* ctx, void* dptr);
+int k16_h2d(k16_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
+int k16_d2h(k16_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
+
+/* ---- timing on the context's stream with HIP events ---- */
+int k16_timer_start(k16_ctx* ctx);
+int k16_timer_stop(k16_ctx* ctx, float* elapsed_ms); /* synchronises */
+/* per-kernel statistics: when enabled, the named hot kernels are bracketed by HIP events.
+ * name: "msm_accumulate", "msm_sort", "msm_reduce", "ntt".  total_ms / launches since reset. */
+int k16_kernel_stats_enable(k16_ctx* ctx, int on);
+int k16_kernel_stats_reset(k16_ctx* ctx);
+int k16_kernel_stats_get(k16_ctx* ctx, const char* name, uint64_t* launches, double* total_ms);
+
+/* ---- multi-scalar multiplication  (multiexp.cpp:183-245) ----
+ * d_bases: n affine points on the device; d_scalars: n x 32 B on the device.
+ * Result: XYZZ point (host memory, 128 B for G1 / 256 B for G2), and/or its affine form.
+ * Any 256-bit scalar is accepted; (0,0) bases contribute nothing; n == 0 gives infinity. */
+int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, void* h_out_xyzz,
+            void* h_out_affine);
+/* same with host buffers (uploads, runs, downloads) */
+int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const void* h_scalars, uint64_t n, void* h_out_xyzz,
+                 void* h_out_affine);
+/* Enqueue only (no host synchronisation): leaves the per-window sums in the context's workspace.
+ * k16_msm_finish() synchronises, downloads them and does the final Horner combine on the host. */
+int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n);
+int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine);
+/* override the window size chosen for the next MSMs (0 = automatic) */
+int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c);
+
+/* combine partial MSM results from several shards/GPUs: out = sum_i parts[i] (XYZZ, host) */
+int k16_points_sum(int group, const void* h_parts_xyzz, uint64_t count, void* h_out_xyzz, void* h_out_affine);
+
+/* ---- NTT over Fr (fft.cpp:192-246), in place on the device, Montgomery form ----
+ * max_domain selects the root table (the reference builds it for 2*domainSize, groth16.hpp:96);
+ * n must be a power of two <= max_domain. inverse != 0 -> FFT::ifft. */
+int k16_ntt(k16_ctx* ctx, void* d_a, uint64_t n, uint64_t max_domain, int inverse);
+int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_domain, int inverse);
+
+/* ---- batch primitives, for parity tests of the device arithmetic ---- */
+int k16_field_op_vec(k16_ctx* ctx, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n);
+int k16_point_op_vec(k16_ctx* ctx, int group, int op, const void* h_p1, const void* h_p2, void* h_r, uint64_t n);
+
+/* ---- Groth16 prover (groth16.cpp:41-360 behind fullprover.cpp:136-250) ----
+ * k16_prover_create parses the zkey (iden3 binfile, sections 1,2,4-9), checks r, and uploads
+ * coefficients and point tables to HBM once.  k16_prover_prove_* run the whole proof on the GPU
+ * and write the compact snarkjs JSON (same bytes as Proof::toJson().dump()).
+ * r_std / s_std: blinding scalars, 32 B standard form, < r.  NULL => drawn from the OS CSPRNG
+ * exactly as groth16.cpp:296-316 does (254-bit candidates, rejection). */
+int  k16_prover_create(k16_ctx* ctx, const char* zkey_path, k16_prover** out);
+int  k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_t zkey_size, k16_prover** out);
+void k16_prover_destroy(k16_prover* p);
+int  k16_prover_info(const k16_prover* p, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain_size,
+                     uint64_t* n_coefs);
+int  k16_prover_prove_file(k16_prover* p, const char* wtns_path, const uint8_t* r_std, const uint8_t* s_std,
+                           char* out_json, size_t cap, float* device_ms);
+/* witness already in memory: n_vars x 32 B standard form (the payload of wtns section 2) */
+int  k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_std,
+                          const uint8_t* s_std, char* out_json, size_t cap, float* device_ms);
+/* debugging / parity: H scalars of the last proof (domain_size x 32 B, standard form) */
+int  k16_prover_last_h(k16_prover* p, void* h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,85 @@
+// ctx.h -- internal context shared by the HIP translation units of libk16.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include <stdint.h>
+#include "../../include/k16.h"
+#include "bn254_curve.h"
+
+struct k16_devbuf {
+    void*  p     = nullptr;
+    size_t bytes = 0;
+};
+
+struct k16_kstat {
+    uint64_t launches = 0;
+    double   total_ms = 0;
+};
+
+struct k16_ntt_table {
+    uint32_t  s      = 0; // log2 size
+    k16::Fr*  roots  = nullptr; // device, 2^s entries, Montgomery
+    k16::Fr   pow2inv[34];
+};
+
+struct k16_ctx {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev_a = nullptr, ev_b = nullptr;     // k16_timer_*
+    hipEvent_t  ks_a = nullptr, ks_b = nullptr;     // kernel stats
+    bool        stats_on = false;
+    std::map<std::string, k16_kstat> stats;
+    std::string err;
+    unsigned    forced_c = 0;
+
+    // MSM workspace (grown on demand, reused across calls)
+    k16_devbuf ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
+        ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan;
+    void* pinned = nullptr; // small pinned host staging buffer
+    size_t pinned_bytes = 0;
+
+    // state of the MSM currently enqueued (k16_msm_enqueue -> k16_msm_finish)
+    int      pend_group = -1;
+    unsigned pend_c = 0, pend_w = 0;
+    uint64_t pend_n = 0;
+
+    std::map<uint32_t, k16_ntt_table> ntt_tables;
+};
+
+#define K16_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return K16_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes);
+
+struct k16_stat_scope {
+    k16_ctx*    ctx;
+    const char* name;
+    bool        on;
+    k16_stat_scope(k16_ctx* c, const char* n) : ctx(c), name(n), on(c->stats_on)
+    {
+        if (on) (void)hipEventRecord(ctx->ks_a, ctx->stream);
+    }
+    ~k16_stat_scope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ctx->ks_b, ctx->stream);
+        (void)hipEventSynchronize(ctx->ks_b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, ctx->ks_a, ctx->ks_b);
+        auto& s = ctx->stats[name];
+        s.launches++;
+        s.total_ms += ms;
+    }
+};
+
+// host-side helpers implemented in msm.hip
+int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out);
+int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse);

@@ -1,0 +1,171 @@
+// msm_api.hip -- C-ABI entry points of the MSM (host side: window choice, Horner combine).
+// Kernels live in msm_kernels.inc, instantiated for G1 in msm_g1.hip and for G2 in msm_g2.hip.
+#include <string.h>
+#include <algorithm>
+#include "ctx.h"
+
+using namespace k16;
+
+int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c);
+int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c);
+
+namespace {
+constexpr unsigned MAX_C = 16;
+constexpr unsigned MIN_C = 4;
+inline unsigned n_windows(unsigned c) { return (256 + c - 1) / c; }
+
+unsigned choose_c(const k16_ctx* ctx, uint64_t n)
+{
+    if (ctx->forced_c >= MIN_C && ctx->forced_c <= MAX_C) return ctx->forced_c;
+    unsigned lg = 0;
+    while ((n >> (lg + 1)) != 0) lg++;
+    int c = (int)lg - 4;
+    if (c < (int)MIN_C) c = MIN_C;
+    if (c > (int)MAX_C) c = MAX_C;
+    return (unsigned)c;
+}
+
+template <class F>
+void horner_host(const Xyzz<F>* win, unsigned W, unsigned c, Xyzz<F>* out)
+{
+    // multiexp.cpp:236-242
+    Xyzz<F> r = win[W - 1];
+    for (int j = (int)W - 2; j >= 0; j--) {
+        for (unsigned k = 0; k < c; k++) r = pdbl(r);
+        r = padd(r, win[j]);
+    }
+    *out = r;
+}
+
+} // namespace
+
+extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
+{
+    if (!ctx) return K16_ERR_ARG;
+    if (c != 0 && (c < MIN_C || c > MAX_C)) return K16_ERR_ARG;
+    ctx->forced_c = c;
+    return K16_OK;
+}
+
+extern "C" int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n)
+{
+    if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+    if (n >= (1ull << 32) / 64) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
+        ctx->err = "k16_msm: n too large for one device call; shard it";
+        return K16_ERR_ARG;
+    }
+    ctx->pend_group = group;
+    ctx->pend_n     = n;
+    if (n == 0) return K16_OK;
+    unsigned c  = choose_c(ctx, n);
+    ctx->pend_c = c;
+    ctx->pend_w = n_windows(c);
+    if (group == K16_G1) return k16_msm_enqueue_g1(ctx, d_bases, d_scalars, n, c);
+    return k16_msm_enqueue_g2(ctx, d_bases, d_scalars, n, c);
+}
+
+extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
+{
+    if (!ctx || ctx->pend_group < 0) return K16_ERR_ARG;
+    int group       = ctx->pend_group;
+    ctx->pend_group = -1;
+    if (ctx->pend_n == 0) {
+        if (group == K16_G1) {
+            G1Xyzz z = G1Xyzz::zero();
+            if (h_out_xyzz) memcpy(h_out_xyzz, &z, sizeof z);
+            if (h_out_affine) memset(h_out_affine, 0, sizeof(G1Aff));
+        } else {
+            G2Xyzz z = G2Xyzz::zero();
+            if (h_out_xyzz) memcpy(h_out_xyzz, &z, sizeof z);
+            if (h_out_affine) memset(h_out_affine, 0, sizeof(G2Aff));
+        }
+        return K16_OK;
+    }
+    K16_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (group == K16_G1) {
+        G1Xyzz r;
+        horner_host<Fq>((const G1Xyzz*)ctx->pinned, ctx->pend_w, ctx->pend_c, &r);
+        if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
+        if (h_out_affine) {
+            G1Aff a = to_affine(r);
+            memcpy(h_out_affine, &a, sizeof a);
+        }
+    } else {
+        G2Xyzz r;
+        horner_host<Fq2>((const G2Xyzz*)ctx->pinned, ctx->pend_w, ctx->pend_c, &r);
+        if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
+        if (h_out_affine) {
+            G2Aff a = to_affine(r);
+            memcpy(h_out_affine, &a, sizeof a);
+        }
+    }
+    return K16_OK;
+}
+
+extern "C" int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n,
+                       void* h_out_xyzz, void* h_out_affine)
+{
+    int rc = k16_msm_enqueue(ctx, group, d_bases, d_scalars, n);
+    if (rc) return rc;
+    return k16_msm_finish(ctx, h_out_xyzz, h_out_affine);
+}
+
+extern "C" int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const void* h_scalars, uint64_t n,
+                            void* h_out_xyzz, void* h_out_affine)
+{
+    if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+    if (n == 0) return k16_msm(ctx, group, nullptr, nullptr, 0, h_out_xyzz, h_out_affine);
+    size_t pb = (size_t)n * (group == K16_G1 ? sizeof(G1Aff) : sizeof(G2Aff));
+    void * db = nullptr, *ds = nullptr;
+    K16_HIP(ctx, hipMalloc(&db, pb));
+    hipError_t e = hipMalloc(&ds, (size_t)n * 32);
+    if (e != hipSuccess) {
+        (void)hipFree(db);
+        ctx->err = "hipMalloc scalars";
+        return K16_ERR_HIP;
+    }
+    int rc = K16_OK;
+    if (hipMemcpyAsync(db, h_bases, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(ds, h_scalars, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        ctx->err = "hipMemcpyAsync h2d";
+        rc       = K16_ERR_HIP;
+    }
+    if (!rc) rc = k16_msm(ctx, group, db, ds, n, h_out_xyzz, h_out_affine);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(db);
+    (void)hipFree(ds);
+    return rc;
+}
+
+extern "C" int k16_points_sum(int group, const void* h_parts, uint64_t count, void* h_out_xyzz, void* h_out_affine)
+{
+    if (group == K16_G1) {
+        G1Xyzz acc = G1Xyzz::zero();
+        for (uint64_t i = 0; i < count; i++) {
+            G1Xyzz p;
+            memcpy(&p, (const char*)h_parts + i * sizeof p, sizeof p);
+            acc = padd(acc, p);
+        }
+        if (h_out_xyzz) memcpy(h_out_xyzz, &acc, sizeof acc);
+        if (h_out_affine) {
+            G1Aff a = to_affine(acc);
+            memcpy(h_out_affine, &a, sizeof a);
+        }
+        return K16_OK;
+    }
+    if (group == K16_G2) {
+        G2Xyzz acc = G2Xyzz::zero();
+        for (uint64_t i = 0; i < count; i++) {
+            G2Xyzz p;
+            memcpy(&p, (const char*)h_parts + i * sizeof p, sizeof p);
+            acc = padd(acc, p);
+        }
+        if (h_out_xyzz) memcpy(h_out_xyzz, &acc, sizeof acc);
+        if (h_out_affine) {
+            G2Aff a = to_affine(acc);
+            memcpy(h_out_affine, &a, sizeof a);
+        }
+        return K16_OK;
+    }
+    return K16_ERR_ARG;
+}

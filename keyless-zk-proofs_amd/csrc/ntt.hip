@@ -1,0 +1,197 @@
+// ntt.hip -- radix-2 NTT / iNTT over BN254 Fr on the device.
+//
+// Replaces FFT<RawFr> (rust-rapidsnark/rapidsnark/src/fft.cpp): root table :40-136, bit-reversal
+// :170-189, in-place DIT stages :192-219, inverse = forward + index reversal + 2^-k scale :222-246.
+// Values are Montgomery-form Fr, 32 B little-endian, exactly as the reference holds them, and the
+// outputs are bit-identical (same roots g^i with g = 5^((r-1)/2^S), same butterfly arithmetic;
+// field results are canonical so evaluation order cannot change them).
+#include <string.h>
+#include "ctx.h"
+
+using namespace k16;
+
+namespace {
+
+__device__ __forceinline__ Fr ld_fr(const Fr* p)
+{
+    Fr           r;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4        a = s[0], b = s[1];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& r)
+{
+    uint4* d = reinterpret_cast<uint4*>(p);
+    d[0]     = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    d[1]     = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// roots[i] = g^i from the table pw[k] = g^(2^k)   (fft.cpp:104-125 builds the same table serially)
+struct PowTable {
+    Fr pw[32];
+};
+__global__ void __launch_bounds__(256) k_build_roots(Fr* __restrict__ roots, uint32_t s, PowTable t)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ull << s)) return;
+    Fr acc = Fr::one();
+    for (uint32_t k = 0; k < s; k++)
+        if ((i >> k) & 1) acc = fmul(acc, t.pw[k]);
+    st_fr(&roots[i], acc);
+}
+
+// fft.cpp:170-189
+__global__ void __launch_bounds__(256) k_bitrev(Fr* __restrict__ a, uint32_t logn)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << logn)) return;
+    uint32_t r = __brev(i) >> (32 - logn);
+    if (i > r) {
+        Fr x = ld_fr(&a[i]), y = ld_fr(&a[r]);
+        st_fr(&a[i], y);
+        st_fr(&a[r], x);
+    }
+}
+
+// fft.cpp:197-218 : one DIT stage, n/2 butterflies
+__global__ void __launch_bounds__(256) k_stage(Fr* __restrict__ a, const Fr* __restrict__ roots, uint32_t logn,
+                                               uint32_t s, uint32_t S)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << (logn - 1))) return;
+    uint32_t md2 = 1u << (s - 1);
+    uint32_t j   = i & (md2 - 1);
+    uint32_t k   = (i >> (s - 1)) << s;
+    Fr       w   = ld_fr(&roots[(size_t)j << (S - s)]);
+    Fr       t   = fmul(w, ld_fr(&a[k + j + md2]));
+    Fr       u   = ld_fr(&a[k + j]);
+    st_fr(&a[k + j], fadd(t, u));
+    st_fr(&a[k + j + md2], fsub(u, t));
+}
+
+// fft.cpp:226-245 : a[i] <-> a[n-i], both scaled by 2^-logn; a[0], a[n/2] scaled in place
+__global__ void __launch_bounds__(256) k_inv_tail(Fr* __restrict__ a, uint32_t logn, Fr scale)
+{
+    uint32_t n = 1u << logn;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > (n >> 1)) return;
+    if (i == 0 || i == (n >> 1)) {
+        if (i < n) st_fr(&a[i], fmul(ld_fr(&a[i]), scale));
+        return;
+    }
+    Fr x = ld_fr(&a[i]), y = ld_fr(&a[n - i]);
+    st_fr(&a[i], fmul(y, scale));
+    st_fr(&a[n - i], fmul(x, scale));
+}
+
+uint32_t ilog2_u64(uint64_t n)
+{
+    uint32_t r = 0;
+    while (n > 1) {
+        n >>= 1;
+        r++;
+    }
+    return r;
+}
+
+} // namespace
+
+// fft.cpp:40-136
+int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out)
+{
+    if (max_domain == 0 || (max_domain & (max_domain - 1))) {
+        ctx->err = "ntt: domain must be a power of two";
+        return K16_ERR_ARG;
+    }
+    uint32_t dp = ilog2_u64(max_domain);
+    if (dp > 28) { // 2-adicity of r (fft.cpp:81-84 "Domain size too big for the curve")
+        ctx->err = "ntt: domain size too big for the curve";
+        return K16_ERR_ARG;
+    }
+    uint32_t s  = dp < 1 ? 1 : dp; // the reference's table always has s >= 1
+    auto     it = ctx->ntt_tables.find(s);
+    if (it != ctx->ntt_tables.end()) {
+        *out = &it->second;
+        return K16_OK;
+    }
+    k16_ntt_table t;
+    t.s = s;
+    // g = 5^((r-1)/2^s)   (nqr = 5 for BN254 r: fft.cpp:60-67)
+    uint32_t e[8];
+    for (int i = 0; i < 8; i++) e[i] = FrParams::P[i];
+    e[0] -= 1; // r - 1 (r is odd, no borrow)
+    for (uint32_t k = 0; k < s; k++) {
+        for (int i = 0; i < 8; i++) e[i] = (e[i] >> 1) | (i < 7 ? e[i + 1] << 31 : 0);
+    }
+    Fr five = Fr::zero();
+    five.v[0] = 5;
+    five      = to_mont(five);
+    Fr       g = fpow(five, e);
+    PowTable pt;
+    pt.pw[0] = g;
+    for (int k = 1; k < 32; k++) pt.pw[k] = fsqr(pt.pw[k - 1]);
+    // powTwoInv[k] = 2^-k (fft.cpp:99-102, 127-130)
+    Fr two = Fr::zero();
+    two.v[0] = 2;
+    Fr half       = finv(to_mont(two));
+    t.pow2inv[0]  = Fr::one();
+    for (int k = 1; k <= 32; k++) t.pow2inv[k] = fmul(t.pow2inv[k - 1], half);
+    K16_HIP(ctx, hipMalloc((void**)&t.roots, sizeof(Fr) << s));
+    uint64_t nr = 1ull << s;
+    hipLaunchKernelGGL(k_build_roots, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, t.roots, s, pt);
+    K16_HIP(ctx, hipGetLastError());
+    auto ins = ctx->ntt_tables.emplace(s, t);
+    *out     = &ins.first->second;
+    return K16_OK;
+}
+
+int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse)
+{
+    if (n == 0 || (n & (n - 1)) || n > (1ull << tab->s)) {
+        ctx->err = "ntt: n must be a power of two <= table size";
+        return K16_ERR_ARG;
+    }
+    uint32_t       logn = ilog2_u64(n);
+    k16_stat_scope ss(ctx, "ntt");
+    if (logn >= 1) {
+        hipLaunchKernelGGL(k_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, logn);
+        for (uint32_t s = 1; s <= logn; s++)
+            hipLaunchKernelGGL(k_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, ctx->stream, d_a,
+                               tab->roots, logn, s, tab->s);
+    }
+    if (inverse) {
+        if (logn == 0) {
+            // n == 1: fft.cpp:243-244 scales a[0] twice (a[0] and a[n>>1] alias) by 2^0 = 1: identity
+        } else {
+            hipLaunchKernelGGL(k_inv_tail, dim3((unsigned)((n / 2 + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_a,
+                               logn, tab->pow2inv[logn]);
+        }
+    }
+    K16_HIP(ctx, hipGetLastError());
+    return K16_OK;
+}
+
+extern "C" int k16_ntt(k16_ctx* ctx, void* d_a, uint64_t n, uint64_t max_domain, int inverse)
+{
+    if (!ctx || !d_a) return K16_ERR_ARG;
+    k16_ntt_table* tab = nullptr;
+    int            rc  = k16_ntt_get_table(ctx, max_domain, &tab);
+    if (rc) return rc;
+    return k16_ntt_enqueue(ctx, (Fr*)d_a, n, tab, inverse);
+}
+
+extern "C" int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_domain, int inverse)
+{
+    if (!ctx || !h_a) return K16_ERR_ARG;
+    void* d = nullptr;
+    K16_HIP(ctx, hipMalloc(&d, n * 32));
+    int rc = K16_OK;
+    if (hipMemcpyAsync(d, h_a, n * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = K16_ERR_HIP;
+    if (!rc) rc = k16_ntt(ctx, d, n, max_domain, inverse);
+    if (!rc && hipMemcpyAsync(h_a, d, n * 32, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = K16_ERR_HIP;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    return rc;
+}

@@ -1,0 +1,536 @@
+// prover.hip -- Groth16 prover for BN254 on one MI355X, behind the C ABI of include/k16.h.
+//
+// Replaces (rust-rapidsnark/rapidsnark/src/):
+//   BinFile / ZKeyUtils::Header / WtnsUtils::Header ... binfile_utils.cpp:13-58, zkey_utils.hpp:49-87,
+//                                                       wtns_utils.hpp:29-44 (same on-disk formats)
+//   Groth16::makeProver / Prover::prove ............... groth16.cpp:18-39, 41-360
+//   Proof::toJson + json::dump ........................ groth16.cpp:378-410, fullprover.cpp:246
+//
+// The zkey is parsed once and its coefficient and point sections are uploaded to HBM once
+// (the reference uses them in place from the mmap).  prove() runs the 4 witness MSMs, the
+// sparse A.w / B.w product, the 3 x (iNTT, coset shift, NTT) chain, the H scalars and the H MSM
+// on the device; the O(1) blinding arithmetic (groth16.cpp:325-352), the affine conversion and
+// the decimal JSON stay on the host, using the same field code (bn254_field.h) compiled for x86.
+#include <fcntl.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include "ctx.h"
+
+using namespace k16;
+
+namespace {
+
+static const uint8_t BN254_R_LE[32] = {0x01, 0x00, 0x00, 0xf0, 0x93, 0xf5, 0xe1, 0x43, 0x91, 0x70, 0xb9,
+                                       0x79, 0x48, 0xe8, 0x33, 0x28, 0x5d, 0x58, 0x81, 0x81, 0xb6, 0x45,
+                                       0x50, 0xb8, 0x29, 0xa0, 0x31, 0xe1, 0x72, 0x4e, 0x64, 0x30};
+
+// ---------------------------------------------------------------- iden3 binfile
+struct Section {
+    const uint8_t* p    = nullptr;
+    uint64_t       size = 0;
+};
+struct BinView {
+    Section sec[16];
+};
+// binfile_utils.cpp:13-58; first occurrence of a section type is "sectionPos 0"
+int parse_binfile(const uint8_t* base, size_t size, const char* type, uint32_t max_version, BinView* out)
+{
+    if (size < 12 || memcmp(base, type, 4) != 0) return K16_ERR_FORMAT;
+    uint32_t version, nsec;
+    memcpy(&version, base + 4, 4);
+    memcpy(&nsec, base + 8, 4);
+    if (version > max_version) return K16_ERR_FORMAT;
+    size_t pos = 12;
+    for (uint32_t i = 0; i < nsec; i++) {
+        if (pos + 12 > size) return K16_ERR_FORMAT;
+        uint32_t st;
+        uint64_t ss;
+        memcpy(&st, base + pos, 4);
+        memcpy(&ss, base + pos + 4, 8);
+        pos += 12;
+        if (ss > size - pos) return K16_ERR_FORMAT;
+        if (st < 16 && out->sec[st].p == nullptr) {
+            out->sec[st].p    = base + pos;
+            out->sec[st].size = ss;
+        }
+        pos += ss;
+    }
+    return K16_OK;
+}
+
+struct MappedFile {
+    uint8_t* base = nullptr;
+    size_t   size = 0;
+    int      fd   = -1;
+    int      open_ro(const char* path)
+    {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return K16_ERR_IO;
+        struct stat sb;
+        if (fstat(fd, &sb) < 0) return K16_ERR_IO;
+        size = (size_t)sb.st_size;
+        if (size == 0) return K16_ERR_FORMAT;
+        void* m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return K16_ERR_IO;
+        base = (uint8_t*)m;
+        return K16_OK;
+    }
+    ~MappedFile()
+    {
+        if (base) munmap(base, size);
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+// ---------------------------------------------------------------- device kernels (F12, F13)
+__device__ __forceinline__ Fr ld_fr(const Fr* p)
+{
+    Fr           r;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4        a = s[0], b = s[1];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& r)
+{
+    uint4* d = reinterpret_cast<uint4*>(p);
+    d[0]     = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    d[1]     = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+
+// groth16.cpp:137-156 : ab[c] += wtns[s] (x) coef.  The zkey's coefficient list is regrouped once at
+// load time into CSR rows (matrix m, constraint c), so each lane owns one output element and no
+// 256-bit atomics / spinlocks are needed.  Field addition is exact, so the summation order is free.
+__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ wire,
+                                              const Fr* __restrict__ coef, const Fr* __restrict__ wtns,
+                                              Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N)
+{
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * N) return;
+    uint32_t lo = row_ptr[t], hi = row_ptr[t + 1];
+    Fr       acc = Fr::zero();
+    for (uint32_t k = lo; k < hi; k++) acc = fadd(acc, fmul(ld_fr(&wtns[wire[k]]), ld_fr(&coef[k])));
+    st_fr(t < N ? &a[t] : &b[t - N], acc);
+}
+// groth16.cpp:160-167
+__global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __restrict__ a, const Fr* __restrict__ b,
+                                             uint32_t N)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) st_fr(&c[i], fmul(ld_fr(&a[i]), ld_fr(&b[i])));
+}
+// groth16.cpp:182-190 : x[i] *= root(log2N + 1, i) = roots[i << (S - log2N - 1)]
+__global__ void __launch_bounds__(256) k_shift(Fr* __restrict__ x, const Fr* __restrict__ roots, uint32_t N,
+                                               uint32_t stride_log)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) st_fr(&x[i], fmul(ld_fr(&x[i]), ld_fr(&roots[(size_t)i << stride_log])));
+}
+// groth16.cpp:266-275 : a = fromMontgomery(a*b - c)
+__global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ a, const Fr* __restrict__ b,
+                                                  const Fr* __restrict__ c, uint32_t N)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) st_fr(&a[i], from_mont(fsub(fmul(ld_fr(&a[i]), ld_fr(&b[i])), ld_fr(&c[i]))));
+}
+
+// ---------------------------------------------------------------- host helpers
+// fq.cpp:225-236 : fromMontgomery then base 10
+std::string fq_to_dec(const Fq& m)
+{
+    Fq       s = from_mont(m);
+    uint32_t w[8];
+    for (int i = 0; i < 8; i++) w[i] = s.v[i];
+    uint32_t chunks[10];
+    int      nch = 0;
+    while (true) {
+        uint32_t any = 0;
+        for (int i = 0; i < 8; i++) any |= w[i];
+        if (!any) break;
+        uint64_t rem = 0;
+        for (int i = 7; i >= 0; i--) {
+            uint64_t cur = (rem << 32) | w[i];
+            w[i]         = (uint32_t)(cur / 1000000000u);
+            rem          = cur % 1000000000u;
+        }
+        chunks[nch++] = (uint32_t)rem;
+    }
+    if (nch == 0) return "0";
+    char buf[100];
+    int  len = snprintf(buf, sizeof buf, "%u", chunks[nch - 1]);
+    for (int i = nch - 2; i >= 0; i--) len += snprintf(buf + len, sizeof buf - len, "%09u", chunks[i]);
+    return std::string(buf, len);
+}
+
+bool geq_r(const uint8_t v[32])
+{
+    for (int i = 31; i >= 0; i--) {
+        if (v[i] != BN254_R_LE[i]) return v[i] > BN254_R_LE[i];
+    }
+    return true;
+}
+// groth16.cpp:296-316 : 32 random bytes, top two bits cleared, rejected while >= r
+int sample_blinding(uint8_t out[32])
+{
+    int fd = ::open("/dev/urandom", O_RDONLY);
+    if (fd < 0) return K16_ERR_IO;
+    do {
+        if (::read(fd, out, 32) != 32) {
+            ::close(fd);
+            return K16_ERR_IO;
+        }
+        out[31] &= 0x3f;
+    } while (geq_r(out));
+    ::close(fd);
+    return K16_OK;
+}
+
+} // namespace
+
+struct k16_prover {
+    k16_ctx* ctx = nullptr;
+    uint32_t n_vars = 0, n_public = 0, domain_size = 0, logN = 0;
+    uint64_t n_coefs = 0;
+    G1Aff    alpha1, beta1, delta1;
+    G2Aff    beta2, delta2;
+    // device-resident key
+    G1Aff *   d_A = nullptr, *d_B1 = nullptr, *d_C = nullptr, *d_H = nullptr;
+    G2Aff*    d_B2    = nullptr;
+    uint32_t *d_rowptr = nullptr, *d_wire = nullptr;
+    Fr*       d_coef  = nullptr;
+    // per-proof buffers
+    Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+    k16_ntt_table* ntt = nullptr;
+    std::vector<uint8_t> last_h;
+};
+
+static void prover_free(k16_prover* p)
+{
+    if (!p) return;
+    void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_B2, p->d_rowptr, p->d_wire, p->d_coef,
+                    p->d_wtns, p->d_a, p->d_b, p->d_c};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete p;
+}
+
+#define K16_HIP_P(ctx, call, p)                                                   \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);       \
+            prover_free(p);                                                       \
+            return K16_ERR_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+
+extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_t zkey_size, k16_prover** out)
+{
+    if (!ctx || !zkey_bytes || !out) return K16_ERR_ARG;
+    *out = nullptr;
+    BinView bv;
+    int     rc = parse_binfile((const uint8_t*)zkey_bytes, zkey_size, "zkey", 1, &bv); // fullprover.cpp:150
+    if (rc) {
+        ctx->err = "zkey: not an iden3 zkey container (type/version/sections)";
+        return rc;
+    }
+    for (int s = 1; s <= 9; s++) {
+        if (s == 3) continue;
+        if (!bv.sec[s].p) {
+            ctx->err = "zkey: missing section";
+            return K16_ERR_FORMAT;
+        }
+    }
+    // zkey_utils.hpp:54-84
+    uint32_t proto = 0;
+    if (bv.sec[1].size < 4) return K16_ERR_FORMAT;
+    memcpy(&proto, bv.sec[1].p, 4);
+    if (proto != 1) {
+        ctx->err = "zkey file is not groth16";
+        return K16_ERR_CURVE; // the reference throws invalid_argument -> UNSUPPORTED_ZKEY_CURVE
+    }
+    const uint8_t* h    = bv.sec[2].p;
+    uint64_t       hsz  = bv.sec[2].size;
+    uint32_t       n8q = 0, n8r = 0;
+    if (hsz < 4) return K16_ERR_FORMAT;
+    memcpy(&n8q, h, 4);
+    if (n8q != 32 || hsz < 4 + 32 + 4) {
+        ctx->err = "zkey curve not supported";
+        return K16_ERR_CURVE;
+    }
+    memcpy(&n8r, h + 4 + n8q, 4);
+    if (n8r != 32 || hsz < 4 + 32 + 4 + 32 + 12 + 64 + 64 + 128 + 128 + 64 + 128 ||
+        memcmp(h + 4 + n8q + 4, BN254_R_LE, 32) != 0) { // fullprover.cpp:154-158
+        ctx->err = "zkey curve not supported";
+        return K16_ERR_CURVE;
+    }
+    h += 4 + n8q + 4 + n8r;
+    k16_prover* p = new k16_prover();
+    p->ctx        = ctx;
+    memcpy(&p->n_vars, h, 4);
+    memcpy(&p->n_public, h + 4, 4);
+    memcpy(&p->domain_size, h + 8, 4);
+    h += 12;
+    memcpy(&p->alpha1, h, 64);
+    h += 64;
+    memcpy(&p->beta1, h, 64);
+    h += 64;
+    memcpy(&p->beta2, h, 128);
+    h += 128 + 128; // gamma2 unused by the prover
+    memcpy(&p->delta1, h, 64);
+    h += 64;
+    memcpy(&p->delta2, h, 128);
+    p->n_coefs = bv.sec[4].size / 44; // zkey_utils.hpp:84 (integer division absorbs the 4-byte count)
+    const uint32_t N = p->domain_size;
+    if (N == 0 || (N & (N - 1)) || p->n_vars == 0 || p->n_public + 1 > p->n_vars) {
+        ctx->err = "zkey: bad header sizes";
+        delete p;
+        return K16_ERR_FORMAT;
+    }
+    while ((1u << p->logN) < N) p->logN++;
+    if (bv.sec[5].size < (uint64_t)p->n_vars * 64 || bv.sec[6].size < (uint64_t)p->n_vars * 64 ||
+        bv.sec[7].size < (uint64_t)p->n_vars * 128 ||
+        bv.sec[8].size < (uint64_t)(p->n_vars - p->n_public - 1) * 64 || bv.sec[9].size < (uint64_t)N * 64 ||
+        bv.sec[4].size < 4 + p->n_coefs * 44) {
+        ctx->err = "zkey: section shorter than the header implies";
+        delete p;
+        return K16_ERR_FORMAT;
+    }
+
+    // regroup coefficients into CSR rows: row id = m * N + c   (Coef layout groth16.hpp:33-42, data at +4)
+    const uint8_t*        cf = bv.sec[4].p + 4;
+    std::vector<uint32_t> rowptr(2 * (size_t)N + 2, 0);
+    for (uint64_t i = 0; i < p->n_coefs; i++) {
+        uint32_t m, c, s;
+        memcpy(&m, cf + i * 44, 4);
+        memcpy(&c, cf + i * 44 + 4, 4);
+        memcpy(&s, cf + i * 44 + 8, 4);
+        if (c >= N || s >= p->n_vars) {
+            ctx->err = "zkey: coefficient index out of range";
+            delete p;
+            return K16_ERR_FORMAT;
+        }
+        uint32_t row = (m == 0 ? 0 : N) + c; // groth16.cpp:147 : m == 0 -> a, else b
+        rowptr[row + 1]++;
+    }
+    for (size_t i = 0; i < 2 * (size_t)N; i++) rowptr[i + 1] += rowptr[i];
+    std::vector<uint32_t> fill(rowptr.begin(), rowptr.end() - 1);
+    std::vector<uint32_t> wire(p->n_coefs ? p->n_coefs : 1);
+    std::vector<uint8_t>  vals((p->n_coefs ? p->n_coefs : 1) * 32);
+    for (uint64_t i = 0; i < p->n_coefs; i++) {
+        uint32_t m, c, s;
+        memcpy(&m, cf + i * 44, 4);
+        memcpy(&c, cf + i * 44 + 4, 4);
+        memcpy(&s, cf + i * 44 + 8, 4);
+        uint32_t pos = fill[(m == 0 ? 0 : N) + c]++;
+        wire[pos]    = s;
+        memcpy(&vals[(size_t)pos * 32], cf + i * 44 + 12, 32);
+    }
+
+    K16_HIP_P(ctx, hipSetDevice(ctx->device), p);
+    const size_t nv = p->n_vars, nc = p->n_vars - p->n_public - 1;
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_A, std::max<size_t>(nv * 64, 64)), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_B1, std::max<size_t>(nv * 64, 64)), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_B2, std::max<size_t>(nv * 128, 128)), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_C, std::max<size_t>(nc * 64, 64)), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_H, (size_t)N * 64), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_rowptr, rowptr.size() * 4), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_wire, wire.size() * 4), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_coef, vals.size()), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_wtns, nv * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_a, (size_t)N * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_b, (size_t)N * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_c, (size_t)N * 32), p);
+    hipStream_t st = ctx->stream;
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_A, bv.sec[5].p, nv * 64, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_B1, bv.sec[6].p, nv * 64, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_B2, bv.sec[7].p, nv * 128, hipMemcpyHostToDevice, st), p);
+    if (nc) K16_HIP_P(ctx, hipMemcpyAsync(p->d_C, bv.sec[8].p, nc * 64, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_H, bv.sec[9].p, (size_t)N * 64, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_wire, wire.data(), wire.size() * 4, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_coef, vals.data(), vals.size(), hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipStreamSynchronize(st), p);
+    // FFT table for 2 * domainSize (groth16.hpp:96)
+    rc = k16_ntt_get_table(ctx, 2ull * N, &p->ntt);
+    if (rc) {
+        prover_free(p);
+        return rc;
+    }
+    K16_HIP_P(ctx, hipStreamSynchronize(st), p);
+    *out = p;
+    return K16_OK;
+}
+
+extern "C" int k16_prover_create(k16_ctx* ctx, const char* zkey_path, k16_prover** out)
+{
+    if (!ctx || !zkey_path || !out) return K16_ERR_ARG;
+    *out = nullptr;
+    MappedFile mf;
+    int        rc = mf.open_ro(zkey_path);
+    if (rc) {
+        ctx->err = std::string("zkey: cannot open/map ") + zkey_path;
+        return rc;
+    }
+    return k16_prover_create_mem(ctx, mf.base, mf.size, out);
+}
+
+extern "C" void k16_prover_destroy(k16_prover* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    prover_free(p);
+}
+
+extern "C" int k16_prover_info(const k16_prover* p, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain_size,
+                               uint64_t* n_coefs)
+{
+    if (!p) return K16_ERR_ARG;
+    if (n_vars) *n_vars = p->n_vars;
+    if (n_public) *n_public = p->n_public;
+    if (domain_size) *domain_size = p->domain_size;
+    if (n_coefs) *n_coefs = p->n_coefs;
+    return K16_OK;
+}
+
+extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in,
+                                    const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
+{
+    if (!p || !h_wtns || !out_json) return K16_ERR_ARG;
+    k16_ctx* ctx = p->ctx;
+    if (n_vars < p->n_vars) { // the reference does not check; reading past the buffer is not an option here
+        ctx->err = "witness has fewer values than the circuit has wires";
+        return K16_ERR_FORMAT;
+    }
+    uint8_t r_std[32], s_std[32];
+    int     rc;
+    if (r_in) {
+        memcpy(r_std, r_in, 32);
+    } else if ((rc = sample_blinding(r_std))) {
+        return rc;
+    }
+    if (s_in) {
+        memcpy(s_std, s_in, 32);
+    } else if ((rc = sample_blinding(s_std))) {
+        return rc;
+    }
+    if (geq_r(r_std) || geq_r(s_std)) {
+        ctx->err = "blinding scalars must be < r";
+        return K16_ERR_ARG;
+    }
+
+    K16_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t    st = ctx->stream;
+    const uint32_t N  = p->domain_size;
+    K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
+
+    // groth16.cpp:88-112 : the four witness MSMs
+    G1Xyzz pi_a, pib1, pi_c, pih;
+    G2Xyzz pi_b;
+    if ((rc = k16_msm(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars, &pi_a, nullptr))) return rc;
+    if ((rc = k16_msm(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars, &pib1, nullptr))) return rc;
+    if ((rc = k16_msm(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars, &pi_b, nullptr))) return rc;
+    if ((rc = k16_msm(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1), (uint64_t)p->n_vars - p->n_public - 1,
+                      &pi_c, nullptr)))
+        return rc;
+
+    // groth16.cpp:116-275 : a, b, c and the H scalars
+    const unsigned gN = (N + 255) / 256;
+    hipLaunchKernelGGL(k_spmv, dim3((2 * N + 255) / 256), dim3(256), 0, st, p->d_rowptr, p->d_wire, p->d_coef,
+                       p->d_wtns, p->d_a, p->d_b, N);
+    hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, st, p->d_c, p->d_a, p->d_b, N);
+    Fr* vec[3] = {p->d_a, p->d_b, p->d_c};
+    for (int k = 0; k < 3; k++) {
+        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 1))) return rc;
+        hipLaunchKernelGGL(k_shift, dim3(gN), dim3(256), 0, st, vec[k], p->ntt->roots, N, p->ntt->s - p->logN - 1);
+        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 0))) return rc;
+    }
+    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, st, p->d_a, p->d_b, p->d_c, N);
+    K16_HIP(ctx, hipGetLastError());
+    // groth16.cpp:281-283
+    if ((rc = k16_msm(ctx, K16_G1, p->d_H, p->d_a, N, &pih, nullptr))) return rc;
+    K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
+    if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
+
+    // groth16.cpp:325-352 : blinding (host; six single scalar multiplications)
+    G1Xyzz d1 = G1Xyzz::from_aff(p->delta1);
+    pi_a      = padd_mixed(pi_a, p->alpha1);
+    pi_a      = padd(pi_a, pmul_scalar(d1, r_std));
+
+    pi_b = padd_mixed(pi_b, p->beta2);
+    pi_b = padd(pi_b, pmul_scalar(G2Xyzz::from_aff(p->delta2), s_std));
+
+    pib1 = padd_mixed(pib1, p->beta1);
+    pib1 = padd(pib1, pmul_scalar(d1, s_std));
+
+    pi_c = padd(pi_c, pih);
+    pi_c = padd(pi_c, pmul_scalar(pi_a, s_std));
+    pi_c = padd(pi_c, pmul_scalar(pib1, r_std));
+    Fr rr, ss;
+    memcpy(rr.v, r_std, 32);
+    memcpy(ss.v, s_std, 32);
+    Fr      rs = to_mont(fmul(rr, ss)); // = r*s mod r in standard form (groth16.cpp:348-349)
+    uint8_t rs_b[32];
+    memcpy(rs_b, rs.v, 32);
+    pi_c = padd(pi_c, pneg(pmul_scalar(d1, rs_b)));
+
+    G1Aff A = to_affine(pi_a), Cc = to_affine(pi_c);
+    G2Aff B = to_affine(pi_b);
+    // groth16.cpp:378-410 + dump(): keys sorted, no whitespace
+    std::string js = "{\"pi_a\":[\"" + fq_to_dec(A.x) + "\",\"" + fq_to_dec(A.y) + "\",\"1\"],\"pi_b\":[[\"" +
+                     fq_to_dec(B.x.a) + "\",\"" + fq_to_dec(B.x.b) + "\"],[\"" + fq_to_dec(B.y.a) + "\",\"" +
+                     fq_to_dec(B.y.b) + "\"],[\"1\",\"0\"]],\"pi_c\":[\"" + fq_to_dec(Cc.x) + "\",\"" +
+                     fq_to_dec(Cc.y) + "\",\"1\"],\"protocol\":\"groth16\"}";
+    if (js.size() + 1 > cap) return K16_ERR_BUFFER;
+    memcpy(out_json, js.c_str(), js.size() + 1);
+    return (int)js.size();
+}
+
+extern "C" int k16_prover_prove_file(k16_prover* p, const char* wtns_path, const uint8_t* r_std, const uint8_t* s_std,
+                                     char* out_json, size_t cap, float* device_ms)
+{
+    if (!p || !wtns_path) return K16_ERR_ARG;
+    k16_ctx*   ctx = p->ctx;
+    MappedFile mf;
+    int        rc = mf.open_ro(wtns_path);
+    if (rc) {
+        ctx->err = std::string("wtns: cannot open/map ") + wtns_path;
+        return rc;
+    }
+    BinView bv;
+    rc = parse_binfile(mf.base, mf.size, "wtns", 2, &bv); // fullprover.cpp:212
+    if (rc || !bv.sec[1].p || !bv.sec[2].p || bv.sec[1].size < 4 + 32 + 4) {
+        ctx->err = "wtns: malformed container";
+        return K16_ERR_FORMAT;
+    }
+    // wtns_utils.hpp:32-40, fullprover.cpp:216-221
+    uint32_t n8 = 0, nv = 0;
+    memcpy(&n8, bv.sec[1].p, 4);
+    if (n8 != 32 || memcmp(bv.sec[1].p + 4, BN254_R_LE, 32) != 0) {
+        ctx->err = "witness uses a different curve than bn128";
+        return K16_ERR_CURVE;
+    }
+    memcpy(&nv, bv.sec[1].p + 4 + 32, 4);
+    uint64_t have = bv.sec[2].size / 32;
+    return k16_prover_prove_mem(p, bv.sec[2].p, have, r_std, s_std, out_json, cap, device_ms);
+}
+
+extern "C" int k16_prover_last_h(k16_prover* p, void* h_out)
+{
+    if (!p || !h_out) return K16_ERR_ARG;
+    k16_ctx* ctx = p->ctx;
+    // after prove(), d_a holds the H scalars (standard form)
+    K16_HIP(ctx, hipMemcpyAsync(h_out, p->d_a, (size_t)p->domain_size * 32, hipMemcpyDeviceToHost, ctx->stream));
+    K16_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return K16_OK;
+}

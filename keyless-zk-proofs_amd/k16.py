@@ -1,0 +1,290 @@
+"""ctypes binding of libk16.so (include/k16.h) -- used by tests/, bench.py and __graft_entry__.py.
+
+There is deliberately no fallback: if the HIP library is missing or no GPU is present,
+loading / context creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libk16.so")
+
+G1, G2 = 0, 1
+FQ, FR = 0, 1
+OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT = range(7)
+PT_ADD, PT_MADD, PT_DBL = range(3)
+AFF_BYTES = {G1: 64, G2: 128}
+XYZZ_BYTES = {G1: 128, G2: 256}
+
+ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -6: "CURVE", -7: "BUFFER"}
+
+# every symbol include/k16.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
+    "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
+    "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
+    "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_set_window_bits", "k16_points_sum",
+    "k16_ntt", "k16_ntt_host", "k16_field_op_vec", "k16_point_op_vec",
+    "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
+    "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
+]
+
+_lib = None
+
+
+class K16Error(RuntimeError):
+    def __init__(self, rc, msg=""):
+        super().__init__("k16 error %s (%d) %s" % (ERR.get(rc, "?"), rc, msg))
+        self.rc = rc
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise K16Error(-1, "libk16.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, u32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_size_t
+    L.k16_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.k16_ctx_destroy.argtypes = [vp]
+    L.k16_ctx_destroy.restype = None
+    L.k16_last_error.argtypes = [vp]
+    L.k16_last_error.restype = C.c_char_p
+    L.k16_sync.argtypes = [vp]
+    L.k16_stream.argtypes = [vp]
+    L.k16_stream.restype = vp
+    L.k16_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.k16_dev_free.argtypes = [vp, vp]
+    L.k16_h2d.argtypes = [vp, vp, vp, sz]
+    L.k16_d2h.argtypes = [vp, vp, vp, sz]
+    L.k16_timer_start.argtypes = [vp]
+    L.k16_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
+    L.k16_kernel_stats_enable.argtypes = [vp, i32]
+    L.k16_kernel_stats_reset.argtypes = [vp]
+    L.k16_kernel_stats_get.argtypes = [vp, C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]
+    L.k16_msm.argtypes = [vp, i32, vp, vp, u64, vp, vp]
+    L.k16_msm_host.argtypes = [vp, i32, vp, vp, u64, vp, vp]
+    L.k16_msm_enqueue.argtypes = [vp, i32, vp, vp, u64]
+    L.k16_msm_finish.argtypes = [vp, vp, vp]
+    L.k16_msm_set_window_bits.argtypes = [vp, u32]
+    L.k16_points_sum.argtypes = [i32, vp, u64, vp, vp]
+    L.k16_ntt.argtypes = [vp, vp, u64, u64, i32]
+    L.k16_ntt_host.argtypes = [vp, vp, u64, u64, i32]
+    L.k16_field_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
+    L.k16_point_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
+    L.k16_prover_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    L.k16_prover_create_mem.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    L.k16_prover_destroy.argtypes = [vp]
+    L.k16_prover_destroy.restype = None
+    L.k16_prover_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
+    L.k16_prover_prove_file.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
+    L.k16_prover_prove_mem.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
+    L.k16_prover_last_h.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return a
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._chk(ctx.L.k16_dev_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.L.k16_h2d(self.ctx.h, self.ptr, _p(arr), arr.nbytes))
+        return self
+
+    def download(self, dtype=np.uint8, shape=None):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.k16_d2h(self.ctx.h, _p(out), self.ptr, self.nbytes))
+        out = out.view(dtype)
+        return out.reshape(shape) if shape is not None else out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.k16_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.k16_ctx_create(device, C.byref(h))
+        if rc:
+            raise K16Error(rc, "k16_ctx_create(device=%d): no usable HIP device" % device)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.k16_ctx_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc:
+            raise K16Error(rc, (self.L.k16_last_error(self.h) or b"").decode())
+
+    def sync(self):
+        self._chk(self.L.k16_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
+
+    def timer_start(self):
+        self._chk(self.L.k16_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.L.k16_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def stats_enable(self, on=True):
+        self._chk(self.L.k16_kernel_stats_enable(self.h, 1 if on else 0))
+
+    def stats_reset(self):
+        self._chk(self.L.k16_kernel_stats_reset(self.h))
+
+    def stats_get(self, name):
+        n, ms = C.c_uint64(), C.c_double()
+        self._chk(self.L.k16_kernel_stats_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def set_window_bits(self, c):
+        self._chk(self.L.k16_msm_set_window_bits(self.h, c))
+
+    # ---- MSM
+    def msm_device(self, group, d_bases, d_scalars, n):
+        x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
+        self._chk(self.L.k16_msm(self.h, group, d_bases.ptr if d_bases else None,
+                                 d_scalars.ptr if d_scalars else None, n, _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    def msm_enqueue(self, group, d_bases, d_scalars, n):
+        self._chk(self.L.k16_msm_enqueue(self.h, group, d_bases.ptr, d_scalars.ptr, n))
+
+    def msm_finish(self, group):
+        x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
+        self._chk(self.L.k16_msm_finish(self.h, _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    def msm(self, group, bases, scalars):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint8)
+        n = scalars.shape[0] if scalars.ndim == 2 else 0
+        x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
+        self._chk(self.L.k16_msm_host(self.h, group, _p(bases), _p(scalars), n, _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    # ---- NTT
+    def ntt(self, a, max_domain=None, inverse=False):
+        a = np.ascontiguousarray(a, dtype=np.uint64).copy()
+        n = a.shape[0]
+        self._chk(self.L.k16_ntt_host(self.h, _p(a), n, max_domain or n, 1 if inverse else 0))
+        return a
+
+    def ntt_device(self, d_a, n, max_domain=None, inverse=False):
+        self._chk(self.L.k16_ntt(self.h, d_a.ptr, n, max_domain or n, 1 if inverse else 0))
+
+    # ---- batch primitives
+    def field_op_vec(self, field, op, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        n = a.shape[0]
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.uint64)
+        r = np.zeros((n, 4), dtype=np.uint64)
+        self._chk(self.L.k16_field_op_vec(self.h, field, op, _p(a), _p(b), _p(r), n))
+        return r
+
+    def point_op_vec(self, group, op, p1, p2=None):
+        p1 = np.ascontiguousarray(p1, dtype=np.uint8)
+        n = p1.shape[0]
+        if p2 is not None:
+            p2 = np.ascontiguousarray(p2, dtype=np.uint8)
+        r = np.zeros((n, XYZZ_BYTES[group]), dtype=np.uint8)
+        self._chk(self.L.k16_point_op_vec(self.h, group, op, _p(p1), _p(p2), _p(r), n))
+        return r
+
+
+def points_sum(group, parts):
+    """parts: uint8 (k, XYZZ_BYTES). Host-side fold of per-shard partial MSM results."""
+    L = load()
+    parts = np.ascontiguousarray(parts, dtype=np.uint8)
+    x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
+    a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
+    rc = L.k16_points_sum(group, _p(parts), parts.shape[0], _p(x), _p(a))
+    if rc:
+        raise K16Error(rc)
+    return x.tobytes(), a.tobytes()
+
+
+class Prover:
+    """Mirror of the reference's FullProver(zkey).prove(wtns) (fullprover.hpp:52-64) over the C ABI."""
+
+    def __init__(self, ctx, zkey_path):
+        self.ctx = ctx
+        h = C.c_void_p()
+        rc = ctx.L.k16_prover_create(ctx.h, zkey_path.encode(), C.byref(h))
+        if rc:
+            raise K16Error(rc, (ctx.L.k16_last_error(ctx.h) or b"").decode())
+        self.h = h
+
+    def info(self):
+        nv, npub, ds, nc = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        self.ctx._chk(self.ctx.L.k16_prover_info(self.h, C.byref(nv), C.byref(npub), C.byref(ds), C.byref(nc)))
+        return dict(n_vars=nv.value, n_public=npub.value, domain_size=ds.value, n_coefs=nc.value)
+
+    def prove_file(self, wtns_path, r=None, s=None):
+        buf = C.create_string_buffer(4096)
+        ms = C.c_float()
+        R_ = np.frombuffer(bytes(r), dtype=np.uint8).copy() if r is not None else None
+        S_ = np.frombuffer(bytes(s), dtype=np.uint8).copy() if s is not None else None
+        rc = self.ctx.L.k16_prover_prove_file(self.h, wtns_path.encode(), _p(R_), _p(S_), buf, 4096, C.byref(ms))
+        if rc < 0:
+            raise K16Error(rc, (self.ctx.L.k16_last_error(self.ctx.h) or b"").decode())
+        self.last_device_ms = ms.value
+        return buf.value.decode()
+
+    def prove_mem(self, wtns, r=None, s=None):
+        wtns = np.ascontiguousarray(wtns, dtype=np.uint8)
+        n_vars = wtns.size // 32
+        buf = C.create_string_buffer(4096)
+        ms = C.c_float()
+        R_ = np.frombuffer(bytes(r), dtype=np.uint8).copy() if r is not None else None
+        S_ = np.frombuffer(bytes(s), dtype=np.uint8).copy() if s is not None else None
+        rc = self.ctx.L.k16_prover_prove_mem(self.h, _p(wtns), n_vars, _p(R_), _p(S_), buf, 4096, C.byref(ms))
+        if rc < 0:
+            raise K16Error(rc, (self.ctx.L.k16_last_error(self.ctx.h) or b"").decode())
+        self.last_device_ms = ms.value
+        return buf.value.decode()
+
+    def last_h(self):
+        n = self.info()["domain_size"]
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.L.k16_prover_last_h(self.h, _p(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx.L.k16_prover_destroy(self.h)
+            self.h = None

@@ -1,0 +1,227 @@
+"""-m gpu : the HIP path, called through the C ABI (libk16.so), against the CPU oracle.
+Bit-exact: integer arithmetic only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import pymodel as pm
+from gpu_common import np_scalars, rand_fe_array
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import k16
+    c = k16.Context(0)   # raises if libk16.so is missing or there is no GPU: no fallback
+    yield c
+    c.close()
+
+
+# ---------------------------------------------------------------- field / curve primitives
+@pytest.mark.parametrize("field", [0, 1])
+def test_field_ops(ctx, field):
+    p = pm.Q if field == 0 else pm.R
+    rng = pm.SplitMix64(77 + field)
+    n = 4096
+    a, b = rand_fe_array(rng, p, n), rand_fe_array(rng, p, n)
+    b[:8] = a[:8][::-1]
+    for op in range(7):
+        got = ctx.field_op_vec(field, op, a, b)
+        want = ol.field_op_vec(field, op, a, b)
+        assert np.array_equal(got, want), (field, op)
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_point_ops_incl_exceptional_cases(ctx, group):
+    """curve.cpp:91-250 branches: inf+P, P+inf, P+P (-> dbl), P+(-P) (-> inf), (0,0) affine operand."""
+    import k16
+    n = 64
+    aff = ol.gen_points(group, 3, n)
+    xb, ab = k16.XYZZ_BYTES[group], k16.AFF_BYTES[group]
+    g = ol.generator(group)
+    # projective operands: k*G in non-trivial XYZZ form (zz != 1)
+    proj = np.zeros((n, xb), dtype=np.uint8)
+    for i in range(n):
+        proj[i] = np.frombuffer(ol.mul_scalar(group, g, pm.limbs(i + 4)), dtype=np.uint8)   # == aff[i] as a point
+    other = np.zeros((n, xb), dtype=np.uint8)
+    for i in range(n):
+        other[i] = np.frombuffer(ol.mul_scalar(group, g, pm.limbs(1000 + 7 * i)), dtype=np.uint8)
+    inf = np.frombuffer(ol.mul_scalar(group, g, pm.limbs(0)), dtype=np.uint8)
+    p1 = other.copy()
+    p2x = proj.copy()
+    p2a = aff.copy()
+    p1[0] = inf                       # inf + P
+    p2x[1] = inf                      # P + inf
+    p2a[1] = 0                        # P + (0,0)
+    p1[2] = proj[2]                   # P + P  -> dbl branch
+    p1[3] = np.frombuffer(ol.pt_op(group, ol.PT_NEG, bytes(proj[3])), dtype=np.uint8)  # P + (-P) -> inf
+    p1[4] = inf
+    p2x[4] = inf
+    p2a[4] = 0                        # inf + inf
+    for op, p2 in ((k16.PT_ADD, p2x), (k16.PT_MADD, p2a), (k16.PT_DBL, None)):
+        got = ctx.point_op_vec(group, op, p1, p2)
+        for i in range(n):
+            want = ol.pt_op(group, {k16.PT_ADD: ol.PT_ADD, k16.PT_MADD: ol.PT_MADD, k16.PT_DBL: ol.PT_DBL}[op],
+                            bytes(p1[i]), bytes(p2[i]) if p2 is not None else None)
+            # same formulas, same branch order => identical XYZZ representation, not just the same point
+            assert bytes(got[i]) == want, (group, op, i)
+
+
+# ---------------------------------------------------------------- MSM
+def _check_msm(ctx, group, bases, scalars, threads=4):
+    _, got = ctx.msm(group, bases, scalars)
+    _, want = ol.msm(group, bases, scalars, nthreads=threads)
+    assert got == want
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 64, 255, 1000])
+@pytest.mark.parametrize("group", [0, 1])
+def test_msm_small(ctx, group, n):
+    bases = ol.gen_points(group, 0, max(n, 1))[:n]
+    scalars = np_scalars(100 + n, n, "full256")
+    if n >= 3:
+        bases[1] = 0                      # (0,0) base is skipped (multiexp.cpp:59)
+        bases[2] = bases[0]               # duplicate base
+        scalars[0] = 0
+    _check_msm(ctx, group, bases, scalars)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "full256", "ones", "zeros", "witness", "topwindow", "same"])
+def test_msm_g1_distributions(ctx, kind):
+    n = 1 << 13
+    bases = ol.gen_points(0, 0, n)
+    _check_msm(ctx, 0, bases, np_scalars(5, n, kind))
+
+
+def test_msm_g1_two_point_kat(ctx):
+    """alt_bn128_test.cpp:215-248 through the HIP path."""
+    bases = [
+        (1626275109576878988287730541908027724405348106427831594181487487855202143055,
+         18706364085805828895917702468512381358405767972162700276238017959231481018884),
+        (17245156998235704504461341147511350131061011207199931581281143511105381019978,
+         3858908536032228066651712470282632925312300188207189106507111128103204506804),
+    ]
+    scalars = [1, 20187316456970436521602619671088988952475789765726813868033071292105413408473]
+    want = (9163953212624378696742080269971059027061360176019470242548968584908855004282,
+            20922060990592511838374895951081914567856345629513259026540392951012456141360)
+    B = np.frombuffer(b"".join(pm.g1_aff_bytes(p) for p in bases), dtype=np.uint8).reshape(2, 64)
+    S = np.frombuffer(b"".join(pm.limbs(s) for s in scalars), dtype=np.uint8).reshape(2, 32)
+    _, aff = ctx.msm(0, B, S)
+    assert pm.g1_aff_from_bytes(aff) == want
+
+
+def test_msm_g1_closed_form_40000(ctx):
+    """alt_bn128_test.cpp:172-212: sum (i+1)*((i+1)G) == (sum (i+1)^2) G."""
+    n = 40000
+    B = ol.gen_points(0, 0, n)
+    S = np.zeros((n, 32), dtype=np.uint8)
+    S[:, :4] = np.arange(1, n + 1, dtype=np.uint32).view(np.uint8).reshape(n, 4)
+    x, _ = ctx.msm(0, B, S)
+    want = ol.mul_scalar(0, ol.generator(0), pm.limbs(sum((i + 1) ** 2 for i in range(n))))
+    assert ol.pt_eq(0, x, want)
+
+
+@pytest.mark.parametrize("c", [4, 7, 11, 13, 16])
+def test_msm_window_sizes_agree(ctx, c):
+    n = 3000
+    bases = ol.gen_points(0, 11, n)
+    scalars = np_scalars(9, n, "full256")
+    ctx.set_window_bits(c)
+    try:
+        _check_msm(ctx, 0, bases, scalars)
+    finally:
+        ctx.set_window_bits(0)
+
+
+def test_msm_g2_medium(ctx):
+    n = 1 << 11
+    bases = ol.gen_points(1, 0, n)
+    _check_msm(ctx, 1, bases, np_scalars(21, n, "uniform"))
+    _check_msm(ctx, 1, bases, np_scalars(22, n, "witness"))
+
+
+def test_msm_g1_2p16_vs_oracle(ctx):
+    n = 1 << 16
+    bases = ol.gen_points(0, 0, n)
+    _check_msm(ctx, 0, bases, np_scalars(31, n, "uniform"), threads=8)
+
+
+def test_msm_g1_full_size_properties(ctx):
+    """BASELINE config 2 size (2^20): closed form and linearity instead of the (slow) oracle."""
+    n = 1 << 20
+    bases = ol.gen_points(0, 0, n)
+    d_b = ctx.to_device(bases)
+    # (1) closed form with scalars i+1
+    S = np.zeros((n, 32), dtype=np.uint8)
+    S[:, :4] = np.arange(1, n + 1, dtype=np.uint32).view(np.uint8).reshape(n, 4)
+    d_s = ctx.to_device(S)
+    x, _ = ctx.msm_device(0, d_b, d_s, n)
+    total = n * (n + 1) * (2 * n + 1) // 6
+    assert ol.pt_eq(0, x, ol.mul_scalar(0, ol.generator(0), pm.limbs(total % pm.R)))
+    # (2) linearity: MSM(s) + MSM(t) == MSM(s + t) for uniform s, t (no modular wrap: both < 2^252)
+    s = np_scalars(1, n, "uniform")
+    t = np_scalars(2, n, "uniform")
+    s[:, 31] &= 0x0F
+    t[:, 31] &= 0x0F
+    s64, t64 = s.view(np.uint64).astype(object), t.view(np.uint64).astype(object)
+    carry = np.zeros(n, dtype=object)
+    u = np.zeros((n, 4), dtype=np.uint64)
+    for k in range(4):
+        tot = s64[:, k] + t64[:, k] + carry
+        u[:, k] = np.array([int(v) & (2 ** 64 - 1) for v in tot], dtype=np.uint64)
+        carry = np.array([int(v) >> 64 for v in tot], dtype=object)
+    xs, _ = ctx.msm_device(0, d_b, d_s.upload(s), n)
+    xt, _ = ctx.msm_device(0, d_b, d_s.upload(t), n)
+    xu, au = ctx.msm_device(0, d_b, d_s.upload(u.view(np.uint8).reshape(n, 32)), n)
+    import k16
+    _, a_sum = k16.points_sum(0, np.frombuffer(xs + xt, dtype=np.uint8).reshape(2, 128))
+    assert a_sum == au
+    d_b.free()
+    d_s.free()
+
+
+# ---------------------------------------------------------------- NTT
+@pytest.mark.parametrize("log2n", [0, 1, 2, 3, 8, 12, 16])
+def test_ntt_vs_oracle(ctx, log2n):
+    n = 1 << log2n
+    rng = pm.SplitMix64(log2n)
+    a = rand_fe_array(rng, pm.R, n, edge=n >= 4)
+    for inverse in (False, True):
+        for md in (n, 2 * n):
+            got = ctx.ntt(a, max_domain=md, inverse=inverse)
+            want = ol.ntt(a, max_domain=md, inverse=inverse)
+            assert np.array_equal(got, want), (log2n, inverse, md)
+
+
+def test_ntt_roundtrip_2p21(ctx):
+    """Keyless domain size: iNTT(NTT(a)) == a (alt_bn128_test.cpp:250-271 at full size)."""
+    n = 1 << 21
+    rs = np.random.RandomState(3)
+    a = rs.randint(0, 2 ** 63, size=(n, 4)).astype(np.uint64)
+    a[:, 3] &= (1 << 60) - 1     # < r
+    f = ctx.ntt(a, max_domain=2 * n)
+    back = ctx.ntt(f, max_domain=2 * n, inverse=True)
+    assert np.array_equal(back, a)
+    assert not np.array_equal(f, a)
+
+
+# ---------------------------------------------------------------- full prove
+def test_toy_proof_bit_exact(ctx, toy_paths):
+    import k16
+    zkey, wtns, vk = toy_paths
+    p = k16.Prover(ctx, zkey)
+    assert p.info() == dict(n_vars=3, n_public=1, domain_size=4, n_coefs=4)
+    for r, s in ((0, 0), (12345, pm.R - 1), (pm.SplitMix64(5).below(pm.R), pm.SplitMix64(6).below(pm.R))):
+        got = p.prove_file(wtns, pm.limbs(r), pm.limbs(s))
+        want = ol.prove_files(zkey, wtns, pm.limbs(r), pm.limbs(s))
+        assert got == want
+    # production path: CSPRNG blinding; proof must verify (reference criterion, prover_handler.rs:279-290)
+    import bn254_pairing as bp
+    js = p.prove_file(wtns)
+    assert bp.verify_json(vk, js, [2])
+    assert js != p.prove_file(wtns)
+    p.close()
