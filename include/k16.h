@@ -101,6 +101,10 @@ int k16_points_sum(int group, const void* h_parts_xyzz, uint64_t count, void* h_
 int k16_ntt(k16_ctx* ctx, void* d_a, uint64_t n, uint64_t max_domain, int inverse);
 int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_domain, int inverse);
 
+/* ---- synthetic inputs: d_out[i] = (start + i + 1) * G, affine Montgomery (the point family of the
+ * reference's own MSM test, alt_bn128_test.cpp:183-190); used by bench.py and the full-size tests ---- */
+int k16_synth_points(k16_ctx* ctx, int group, uint64_t start, uint64_t n, void* d_out_affine);
+
 /* ---- batch primitives, for parity tests of the device arithmetic ---- */
 int k16_field_op_vec(k16_ctx* ctx, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n);
 int k16_point_op_vec(k16_ctx* ctx, int group, int op, const void* h_p1, const void* h_p2, void* h_r, uint64_t n);

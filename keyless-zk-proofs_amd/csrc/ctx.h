@@ -28,7 +28,10 @@ struct k16_ctx {
     int         device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t  ev_a = nullptr, ev_b = nullptr;     // k16_timer_*
-    hipEvent_t  ks_a = nullptr, ks_b = nullptr;     // kernel stats
+    // kernel stats: event pairs are recorded without synchronising; resolved in k16_kernel_stats_get
+    std::vector<hipEvent_t> ks_pool;
+    std::vector<std::pair<std::string, size_t>> ks_pending; // (name, index of the start event in ks_pool)
+    size_t      ks_used = 0;
     bool        stats_on = false;
     std::map<std::string, k16_kstat> stats;
     std::string err;
@@ -59,24 +62,21 @@ struct k16_ctx {
 
 int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes);
 
+void k16_stats_begin(k16_ctx* ctx, const char* name);
+void k16_stats_end(k16_ctx* ctx);
+int  k16_stats_resolve(k16_ctx* ctx);
+
+// brackets a group of launches with a HIP event pair on the context's stream (no host sync)
 struct k16_stat_scope {
-    k16_ctx*    ctx;
-    const char* name;
-    bool        on;
-    k16_stat_scope(k16_ctx* c, const char* n) : ctx(c), name(n), on(c->stats_on)
+    k16_ctx* ctx;
+    bool     on;
+    k16_stat_scope(k16_ctx* c, const char* n) : ctx(c), on(c->stats_on)
     {
-        if (on) (void)hipEventRecord(ctx->ks_a, ctx->stream);
+        if (on) k16_stats_begin(ctx, n);
     }
     ~k16_stat_scope()
     {
-        if (!on) return;
-        (void)hipEventRecord(ctx->ks_b, ctx->stream);
-        (void)hipEventSynchronize(ctx->ks_b);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, ctx->ks_a, ctx->ks_b);
-        auto& s = ctx->stats[name];
-        s.launches++;
-        s.total_ms += ms;
+        if (on) k16_stats_end(ctx);
     }
 };
 

@@ -30,8 +30,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     k16_ctx* c = new k16_ctx();
     c->device  = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess ||
-        hipEventCreate(&c->ks_a) != hipSuccess || hipEventCreate(&c->ks_b) != hipSuccess) {
+        hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
         delete c;
         return K16_ERR_NO_DEVICE;
     }
@@ -59,8 +58,7 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipEventDestroy(c->ev_a);
     (void)hipEventDestroy(c->ev_b);
-    (void)hipEventDestroy(c->ks_a);
-    (void)hipEventDestroy(c->ks_b);
+    for (hipEvent_t e : c->ks_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -116,21 +114,59 @@ extern "C" int k16_timer_stop(k16_ctx* c, float* ms)
     K16_HIP(c, hipEventElapsedTime(ms, c->ev_a, c->ev_b));
     return K16_OK;
 }
+void k16_stats_begin(k16_ctx* c, const char* name)
+{
+    if (c->ks_used + 2 > c->ks_pool.size()) {
+        for (int i = 0; i < 64; i++) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            c->ks_pool.push_back(e);
+        }
+    }
+    c->ks_pending.emplace_back(name, c->ks_used);
+    (void)hipEventRecord(c->ks_pool[c->ks_used], c->stream);
+    c->ks_used += 2;
+}
+void k16_stats_end(k16_ctx* c)
+{
+    if (c->ks_pending.empty()) return;
+    (void)hipEventRecord(c->ks_pool[c->ks_pending.back().second + 1], c->stream);
+}
+int k16_stats_resolve(k16_ctx* c)
+{
+    if (c->ks_pending.empty()) return K16_OK;
+    K16_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& pr : c->ks_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ks_pool[pr.second], c->ks_pool[pr.second + 1]) == hipSuccess) {
+            auto& s = c->stats[pr.first];
+            s.launches++;
+            s.total_ms += ms;
+        }
+    }
+    c->ks_pending.clear();
+    c->ks_used = 0;
+    return K16_OK;
+}
 extern "C" int k16_kernel_stats_enable(k16_ctx* c, int on)
 {
     if (!c) return K16_ERR_ARG;
+    int rc = k16_stats_resolve(c);
     c->stats_on = on != 0;
-    return K16_OK;
+    return rc;
 }
 extern "C" int k16_kernel_stats_reset(k16_ctx* c)
 {
     if (!c) return K16_ERR_ARG;
+    int rc = k16_stats_resolve(c);
     c->stats.clear();
-    return K16_OK;
+    return rc;
 }
 extern "C" int k16_kernel_stats_get(k16_ctx* c, const char* name, uint64_t* launches, double* total_ms)
 {
     if (!c || !name) return K16_ERR_ARG;
+    int rc = k16_stats_resolve(c);
+    if (rc) return rc;
     auto it = c->stats.find(name);
     if (launches) *launches = it == c->stats.end() ? 0 : it->second.launches;
     if (total_ms) *total_ms = it == c->stats.end() ? 0.0 : it->second.total_ms;
@@ -171,6 +207,60 @@ __global__ void k_point_op(int op, const Xyzz<F>* __restrict__ p1, const void* _
     default: z = Xyzz<F>::zero();
     }
     r[i] = z;
+}
+
+// Synthetic point table: out[i] = (start + i + 1) * G, affine Montgomery -- the deterministic bases of
+// SURVEY 8(d) (the reference's own MSM test uses the same family, alt_bn128_test.cpp:183-190).
+template <class F>
+__global__ void __launch_bounds__(64) k_synth_points(Aff<F> gen, uint64_t start, uint64_t n, Aff<F>* __restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k   = start + i + 1;
+    Xyzz<F>  acc = Xyzz<F>::zero();
+#pragma clang loop unroll(disable)
+    for (int b = 63; b >= 0; b--) {
+        acc = pdbl(acc);
+        if ((k >> b) & 1) acc = padd_mixed(acc, gen);
+    }
+    out[i] = to_affine(acc);
+}
+
+extern "C" int k16_synth_points(k16_ctx* c, int group, uint64_t start, uint64_t n, void* d_out_affine)
+{
+    if (!c || !d_out_affine || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+    if (n == 0) return K16_OK;
+    unsigned grid = (unsigned)((n + 63) / 64);
+    if (group == K16_G1) {
+        G1Aff g;
+        g.x = Fq::one();                 // generator (1, 2)  (alt_bn128.hpp:41)
+        g.y = fdbl(Fq::one());
+        hipLaunchKernelGGL((k_synth_points<Fq>), dim3(grid), dim3(64), 0, c->stream, g, start, n, (G1Aff*)d_out_affine);
+    } else {
+        // G2 generator (alt_bn128.hpp:43-52): decimal constants converted on the host
+        static const char* const G2S[4] = {
+            "10857046999023057135944570762232829481370756359578518086990519993285655852781",
+            "11559732032986387107991004021392285783925812861821192530917403151452391805634",
+            "8495653923123431417604973247489272438418190587263600148770280649306958101930",
+            "4082367875863433681332203403145435568316851327593401208105741076214120093531"};
+        Fq v[4];
+        Fq ten = Fq::zero();
+        ten.v[0] = 10;
+        ten      = to_mont(ten);
+        for (int k = 0; k < 4; k++) {
+            Fq acc = Fq::zero();
+            for (const char* p = G2S[k]; *p; p++) {
+                Fq d  = Fq::zero();
+                d.v[0] = (uint32_t)(*p - '0');
+                acc   = fadd(fmul(acc, ten), to_mont(d));
+            }
+            v[k] = acc;
+        }
+        G2Aff g{Fq2{v[0], v[1]}, Fq2{v[2], v[3]}};
+        hipLaunchKernelGGL((k_synth_points<Fq2>), dim3(grid), dim3(64), 0, c->stream, g, start, n, (G2Aff*)d_out_affine);
+    }
+    K16_HIP(c, hipGetLastError());
+    return K16_OK;
 }
 
 extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n)

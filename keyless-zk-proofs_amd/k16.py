@@ -26,7 +26,7 @@ SYMBOLS = [
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_set_window_bits", "k16_points_sum",
-    "k16_ntt", "k16_ntt_host", "k16_field_op_vec", "k16_point_op_vec",
+    "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
 ]
@@ -73,6 +73,7 @@ def load():
     L.k16_points_sum.argtypes = [i32, vp, u64, vp, vp]
     L.k16_ntt.argtypes = [vp, vp, u64, u64, i32]
     L.k16_ntt_host.argtypes = [vp, vp, u64, u64, i32]
+    L.k16_synth_points.argtypes = [vp, i32, u64, u64, vp]
     L.k16_field_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
     L.k16_point_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
     L.k16_prover_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
@@ -195,6 +196,13 @@ class Context:
         a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
         self._chk(self.L.k16_msm_host(self.h, group, _p(bases), _p(scalars), n, _p(x), _p(a)))
         return x.tobytes(), a.tobytes()
+
+    def synth_points(self, group, start, n):
+        """Device buffer with (start+i+1)*G, i < n (affine Montgomery)."""
+        d = self.alloc(max(n * AFF_BYTES[group], 16))
+        self._chk(self.L.k16_synth_points(self.h, group, start, n, d.ptr))
+        self.sync()
+        return d
 
     # ---- NTT
     def ntt(self, a, max_domain=None, inverse=False):
