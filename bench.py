@@ -110,18 +110,13 @@ def main():
     scalars = uniform_scalars(n, seed=0xD1B5 + rank)
     d_scalars = ctx.to_device(scalars)
 
-    gather_buf = None
-    if dist is not None:
-        gather_buf = [torch.empty(128, dtype=torch.uint8, device="cuda") for _ in range(world)]
+    import sharding
 
     def step():
         ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
         xyzz, _ = ctx.msm_finish(k16.G1)
         if dist is not None:
-            mine = torch.frombuffer(bytearray(xyzz), dtype=torch.uint8).cuda()
-            dist.all_gather(gather_buf, mine)
-            parts = torch.stack(gather_buf).cpu().numpy()
-            xyzz, _ = k16.points_sum(k16.G1, parts)
+            xyzz, _ = sharding.exchange_and_fold(dist, k16.G1, xyzz, device="cuda")
         return xyzz
 
     for _ in range(args.warmup):

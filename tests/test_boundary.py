@@ -1,0 +1,113 @@
+"""Drop-in boundary: the C-ABI library loads and exports every symbol include/k16.h declares, the
+C++ FullProver facade keeps the reference's ABI, and both fail loudly (never fall back) without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "keyless-zk-proofs_amd")
+LIB = os.path.join(PKG, "libk16.so")
+HARNESS_SRC = os.path.join(ROOT, "tests", "cpp", "fullprover_harness.cpp")
+
+
+def _has_gpu():
+    try:
+        import k16
+        c = k16.Context(0)
+        c.close()
+        return True
+    except Exception:
+        return False
+
+
+def build_harness(tmp_path):
+    exe = str(tmp_path / "fullprover_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), HARNESS_SRC,
+                           "-L", PKG, "-lk16", "-Wl,-rpath," + PKG, "-o", exe])
+    return exe
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(LIB), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    hdr = open(os.path.join(ROOT, "include", "k16.h")).read()
+    declared = set(re.findall(r"\b(k16_[a-z0-9_]+)\s*\(", hdr))
+    import k16
+    assert declared == set(k16.SYMBOLS), declared ^ set(k16.SYMBOLS)
+    L = ctypes.CDLL(LIB)
+    for s in sorted(declared):
+        assert hasattr(L, s), s
+    # C++ facade: Itanium-mangled entry points bindgen binds (rust-rapidsnark/build.rs:142-146)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", LIB]).decode()
+    for m in ("_ZN10FullProverC1EPKc", "_ZN10FullProverD1Ev", "_ZNK10FullProver5proveEPKc",
+              "_ZN14ProverResponseC1E11ProverError", "_ZN14ProverResponseD1Ev"):
+        assert m in syms, m
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU behaviour")
+def test_no_gpu_fails_loudly_no_fallback(tmp_path, toy_paths):
+    import k16
+    with pytest.raises(k16.K16Error) as ei:
+        k16.Context(0)
+    assert ei.value.rc == -1
+    zkey, wtns, _ = toy_paths
+    exe = build_harness(tmp_path)
+    out = subprocess.run([exe, zkey, wtns], capture_output=True, text=True, timeout=120)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=1"                       # not OK
+    assert lines[1].startswith("type=1 error=1")       # ERROR / PROVER_NOT_READY (fullprover.cpp:117-121)
+    assert lines[2] == ""                              # raw_json = ""
+    assert "no CPU fallback" in out.stderr
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under keyless-zk-proofs_amd/ or include/ may reference it."""
+    bad = []
+    for base in (PKG, os.path.join(ROOT, "include")):
+        for dp, _, fns in os.walk(base):
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"oracle_lib|liboracle|oracle/|bn254_ref|ora_[a-z]+\(", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_fullprover_facade_on_gpu(tmp_path, toy_paths):
+    import json
+    import bn254_pairing as bp
+    zkey, wtns, vk = toy_paths
+    exe = build_harness(tmp_path)
+    out = subprocess.run([exe, zkey, wtns, "3"], capture_output=True, text=True, timeout=300)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr
+    proofs = []
+    for k in range(3):
+        assert lines[1 + 2 * k].startswith("type=0 error=0 ms="), lines
+        proofs.append(lines[2 + 2 * k])
+    assert len(set(proofs)) == 3                      # fresh CSPRNG blinding each time
+    for js in proofs:
+        assert json.loads(js)["protocol"] == "groth16"
+        assert bp.verify_json(vk, js, [2])            # reference criterion: prover_handler.rs:279-290
+    # error mapping (fullprover.cpp:91-100, 117-121, 216-221)
+    missing = subprocess.run([exe, str(tmp_path / "nope.zkey"), wtns], capture_output=True, text=True, timeout=120)
+    assert missing.stdout.splitlines()[0] == "state=1"          # ZKEY_FILE_LOAD_ERROR
+    assert missing.stdout.splitlines()[1].startswith("type=1 error=1")
+    wrong = subprocess.run([exe, wtns, wtns], capture_output=True, text=True, timeout=120)
+    assert wrong.stdout.splitlines()[0] == "state=2"            # UNSUPPORTED_ZKEY_CURVE (wrong container type)
+    garbage = tmp_path / "bad.wtns"
+    garbage.write_bytes(b"wtns" + b"\x02\0\0\0" + b"\x01\0\0\0" + b"\xff" * 20)
+    bad = subprocess.run([exe, zkey, str(garbage)], capture_output=True, text=True, timeout=120)
+    assert bad.stdout.splitlines()[1].startswith("type=1 error=2")  # INVALID_INPUT
+    # a witness over another prime -> WITNESS_GENERATION_INVALID_CURVE
+    w = bytearray(open(wtns, "rb").read())
+    i = w.index(bytes.fromhex("010000f093f5e143"))
+    w[i] ^= 0x02
+    other = tmp_path / "othercurve.wtns"
+    other.write_bytes(bytes(w))
+    oc = subprocess.run([exe, zkey, str(other)], capture_output=True, text=True, timeout=120)
+    assert oc.stdout.splitlines()[1].startswith("type=1 error=3")
