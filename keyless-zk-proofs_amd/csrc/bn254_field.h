@@ -152,6 +152,43 @@ K16_HD Fp<PR> fdbl(const Fp<PR>& a)
 template <class PR>
 K16_HD Fp<PR> fmul(const Fp<PR>& a, const Fp<PR>& b)
 {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host build (blinding step, Horner tail, affine/JSON): the same CIOS on 4 x 64-bit words
+    typedef unsigned __int128 u128;
+    uint64_t A[4], B[4], P[4], t[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        A[i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+        B[i] = (uint64_t)b.v[2 * i] | ((uint64_t)b.v[2 * i + 1] << 32);
+        P[i] = (uint64_t)PR::P[2 * i] | ((uint64_t)PR::P[2 * i + 1] << 32);
+    }
+    // -p^-1 mod 2^64 from the 32-bit constant by one Newton step: x' = x * (2 + p*x)  (x = -p^-1)
+    uint64_t np = (uint64_t)PR::NP;
+    np          = np * (2 + P[0] * np);
+    for (int i = 0; i < 4; i++) {
+        u128     X = (u128)A[0] * B[i] + t[0];
+        uint64_t m = (uint64_t)X * np;
+        u128     C = (u128)m * P[0] + (uint64_t)X;
+        X >>= 64;
+        C >>= 64;
+        for (int j = 1; j < 4; j++) {
+            X += (u128)A[j] * B[i] + t[j];
+            C += (u128)m * P[j] + (uint64_t)X;
+            t[j - 1] = (uint64_t)C;
+            X >>= 64;
+            C >>= 64;
+        }
+        t[3] = (uint64_t)(X + C);
+    }
+    uint32_t r32[8];
+    for (int i = 0; i < 4; i++) {
+        r32[2 * i]     = (uint32_t)t[i];
+        r32[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    cond_sub_p<PR>(r32);
+    Fp<PR> r;
+    for (int i = 0; i < 8; i++) r.v[i] = r32[i];
+    return r;
+#else
     uint32_t t[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = 0;
@@ -177,6 +214,7 @@ K16_HD Fp<PR> fmul(const Fp<PR>& a, const Fp<PR>& b)
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = t[i];
     return r;
+#endif
 }
 template <class PR>
 K16_HD Fp<PR> fsqr(const Fp<PR>& a)

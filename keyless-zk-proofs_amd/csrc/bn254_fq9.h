@@ -1,0 +1,334 @@
+// bn254_fq9.h -- BN254 Fq in an unsaturated radix-2^29 representation (9 limbs), for the EC hot loops.
+//
+// Why: gfx950's integer multiplier is v_mad_u64_u32 (32x32+64 -> 64, half rate) and every carry
+// (v_add_co / v_addc) costs about as much as a multiply-add (profiles/r01/ubench_instruction_rates.log).
+// With 29-bit limbs a 64-bit accumulator can absorb all 18 partial products of a column
+// (18 * 2^58 < 2^63), so a Montgomery multiplication is 162 carry-free multiply-adds plus one
+// shift/mask per column -- 1.9x the throughput of the canonical 8 x 32-bit CIOS (bn254_field.h).
+//
+// Semantics.  An Fq9 holds an integer V = sum l[i] * 2^(29 i) with l[0..7] < 2^29 ("normalised"),
+// congruent mod p to x * R' where R' = 2^261 (Montgomery form for THIS radix).  V is NOT kept
+// canonical: each function documents the bound (as a multiple of p) it needs and returns; p < 2^254
+// and R'/p ~ 169, so  fmul9(a, b) < p * (1 + A*B/169)  for a < A*p, b < B*p  -- i.e. < 2p whenever
+// A*B <= 128, with no final conditional subtraction at all.  Additions and subtractions just add
+// limbs (plus a multiple of p for subtraction) and renormalise.  Conversions to and from the
+// reference's canonical Montgomery form (R = 2^256, fq_raw_generic.cpp) are exact, so the group
+// elements computed here are the same as with bn254_field.h; only the schedule of reductions differs.
+#pragma once
+#include "bn254_field.h"
+
+namespace k16 {
+
+struct Fq9 {
+    uint32_t l[9];
+};
+
+namespace fq9c {
+constexpr uint32_t MASK = (1u << 29) - 1;
+// p in radix 2^29
+constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                           0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+constexpr uint32_t NP   = 0x04866389u; // -p^-1 mod 2^29
+// R' mod p  (Montgomery one)
+constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                             0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+// 2^266 mod p = R'^2 / R : fmul9(x*R, K_IN) = x*R'
+constexpr uint32_t K_IN[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u,
+                              0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+// 2^256 mod p = R : fmul9(x*R', K_OUT) = x*R
+constexpr uint32_t K_OUT[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
+                               0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+// k*p for the subtraction offsets
+constexpr uint32_t KP2[9] = {0x10f9fa8eu, 0x0208c16du, 0x18e5469eu, 0x05aa45a1u, 0x0b0bb2f0u,
+                             0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+constexpr uint32_t KP4[9] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u,
+                             0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+constexpr uint32_t KP8[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u,
+                             0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
+} // namespace fq9c
+
+K16_HD Fq9 fq9_zero()
+{
+    Fq9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = 0;
+    return r;
+}
+K16_HD Fq9 fq9_one()
+{
+    Fq9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = fq9c::ONE[i];
+    return r;
+}
+K16_HD bool fq9_limbs_zero(const Fq9& a)
+{
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i];
+    return o == 0;
+}
+
+// Montgomery product for radix 2^29: returns a*b/R' mod p, < p*(1 + A*B/169); limbs normalised.
+// Needs normalised inputs (l[0..7] < 2^29, l[8] < 2^29).  Product scanning; column k collects the
+// a_i*b_j with i+j = k and the m_i*p_j reduction terms; m_k clears the low 29 bits of column k.
+K16_HD Fq9 fmul9(const Fq9& a, const Fq9& b)
+{
+    uint32_t m[9];
+    Fq9      r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc2 = 0; // second chain: halves the dependent-multiply-add depth per column
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            acc += (uint64_t)a.l[i] * b.l[j];
+            if (i < k || k >= 9) {
+                if (i <= 8 && (k >= 9 || i < k)) acc2 += (uint64_t)m[i] * fq9c::P[j];
+            }
+        }
+        acc += acc2;
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * fq9c::NP) & fq9c::MASK;
+            acc += (uint64_t)m[k] * fq9c::P[0];
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & fq9c::MASK;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+K16_HD Fq9 fsqr9(const Fq9& a) { return fmul9(a, a); }
+
+// a + b (bound A + B); limbs renormalised
+K16_HD Fq9 fadd9(const Fq9& a, const Fq9& b)
+{
+    Fq9      r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t t = a.l[i] + b.l[i] + c;
+        r.l[i]     = t & fq9c::MASK;
+        c          = t >> 29;
+    }
+    r.l[8] = a.l[8] + b.l[8] + c;
+    return r;
+}
+K16_HD Fq9 fdbl9(const Fq9& a) { return fadd9(a, a); }
+
+// a - b + K*p, K in {2, 4, 8}; needs b < K*p; result < A + K.  Signed limb-wise difference with an
+// arithmetic-shift carry; the total is non-negative so the top limb ends >= 0.
+template <int K>
+K16_HD Fq9 fsub9(const Fq9& a, const Fq9& b)
+{
+    Fq9     r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t kp = K == 2 ? fq9c::KP2[i] : (K == 4 ? fq9c::KP4[i] : fq9c::KP8[i]);
+        int32_t        t  = (int32_t)(a.l[i] + kp) - (int32_t)b.l[i] + c;
+        if (i < 8) {
+            r.l[i] = (uint32_t)t & fq9c::MASK;
+            c      = t >> 29;
+        } else {
+            r.l[8] = (uint32_t)t;
+        }
+    }
+    return r;
+}
+
+// exact comparison with j*p, j = 0 .. J-1, for a normalised value < J*p:  V == 0 (mod p) ?
+// Prefilter on the low limb (false positives ~ J / 2^29), then a full 9-limb compare.
+template <int J>
+K16_HD bool fq9_is_zero_mod_p(const Fq9& a)
+{
+    static_assert(J <= 12, "bound too large");
+    bool hit = false;
+    // j*p mod 2^29
+    constexpr uint32_t JP0[12] = {0x00000000u, 0x187cfd47u, 0x10f9fa8eu, 0x0976f7d5u, 0x01f3f51cu, 0x1a70f263u,
+                                  0x12edefaau, 0x0b6aecf1u, 0x03e7ea38u, 0x1c64e77fu, 0x14e1e4c6u, 0x0d5ee20du};
+#pragma unroll
+    for (int j = 0; j < J; j++) hit |= a.l[0] == JP0[j];
+    if (!hit) return false;
+    // slow path: subtract p until the value is below p (at most J-1 times), then test for zero
+    Fq9 v = a;
+    for (int j = 0; j < J; j++) {
+        // v >= p ?
+        bool ge = true;
+        for (int i = 8; i >= 0; i--) {
+            if (v.l[i] != fq9c::P[i]) {
+                ge = v.l[i] > fq9c::P[i];
+                break;
+            }
+        }
+        if (!ge) break;
+        int32_t c = 0;
+        for (int i = 0; i < 9; i++) {
+            int32_t t = (int32_t)v.l[i] - (int32_t)fq9c::P[i] + c;
+            if (i < 8) {
+                v.l[i] = (uint32_t)t & fq9c::MASK;
+                c      = t >> 29;
+            } else {
+                v.l[8] = (uint32_t)t;
+            }
+        }
+    }
+    return fq9_limbs_zero(v);
+}
+
+// ---- packing: 9 x 29-bit limbs <-> 8 x 32-bit words (value must be < 2^256)
+K16_HD Fq9 fq9_unpack(const uint32_t w[8])
+{
+    Fq9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int bit = 29 * i, wd = bit >> 5, sh = bit & 31;
+        uint64_t  v = w[wd];
+        if (wd + 1 < 8) v |= (uint64_t)w[wd + 1] << 32;
+        r.l[i] = (uint32_t)(v >> sh) & (i < 8 ? fq9c::MASK : 0xffffffffu);
+    }
+    return r;
+}
+K16_HD void fq9_pack(uint32_t w[8], const Fq9& a)
+{
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // word k covers bits [32k, 32k+32)
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int lo = 29 * i - 32 * k; // position of limb i relative to word k
+            if (lo > -29 && lo < 32) v |= lo >= 0 ? ((uint64_t)a.l[i] << lo) : ((uint64_t)a.l[i] >> (-lo));
+        }
+        w[k] = (uint32_t)v;
+    }
+}
+
+// canonical Montgomery (R = 2^256, 8 x u32, < p)  ->  Fq9 (R' domain, < 2p)
+K16_HD Fq9 fq9_from_fq(const Fq& x)
+{
+    Fq9 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = fq9c::K_IN[i];
+    return fmul9(fq9_unpack(x.v), k);
+}
+// Fq9 (any bound <= 12p)  ->  canonical Montgomery Fq (< p)
+K16_HD Fq fq9_to_fq(const Fq9& a)
+{
+    Fq9 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = fq9c::K_OUT[i];
+    Fq9 v = fmul9(a, k); // = x*R, < 2p
+    Fq  r;
+    fq9_pack(r.v, v);
+    cond_sub_p<FqParams>(r.v);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// G1 in XYZZ coordinates over Fq9.  Same formulas and the same exceptional-case order as
+// bn254_curve.h (curve.cpp:91-458 of the reference).  Invariant of every stored point:
+//     X < 8p,  Y < 4p,  ZZ < 2p,  ZZZ < 2p          (affine table entries: x, y < 2p)
+// Bounds in the comments are multiples of p; every product obeys A*B <= 128.
+// ------------------------------------------------------------------------------------------------
+struct Aff9 {
+    Fq9 x, y;
+    K16_HD bool is_zero() const { return fq9_limbs_zero(x) && fq9_limbs_zero(y); } // (0,0) converts to exact zero limbs
+};
+struct Xyzz9 {
+    Fq9 x, y, zz, zzz;
+    K16_HD bool         is_zero() const { return fq9_is_zero_mod_p<2>(zz); }
+    static K16_HD Xyzz9 zero() { return Xyzz9{fq9_one(), fq9_one(), fq9_zero(), fq9_zero()}; }
+    static K16_HD Xyzz9 from_aff(const Aff9& a)
+    {
+        if (a.is_zero()) return zero();
+        return Xyzz9{a.x, a.y, fq9_one(), fq9_one()};
+    }
+};
+
+// curve.cpp:411-458
+K16_HD Xyzz9 pdbl_aff9(const Aff9& p)
+{
+    if (p.is_zero()) return Xyzz9::zero();
+    Fq9 U  = fdbl9(p.y);                            // 4
+    Fq9 V  = fsqr9(U);                              // 16 -> 2
+    Fq9 W  = fmul9(U, V);                           // 8  -> 2
+    Fq9 S  = fmul9(p.x, V);                         // 4  -> 2
+    Fq9 M  = fsqr9(p.x);                            // 4  -> 2
+    M      = fadd9(fdbl9(M), M);                    // 6
+    Fq9 X3 = fsub9<4>(fsqr9(M), fdbl9(S));          // 36 -> 2 ; - 2S (<4) -> 6
+    Fq9 Y3 = fsub9<2>(fmul9(M, fsub9<8>(S, X3)), fmul9(W, p.y)); // (S - X3 + 8p) < 10 ; 6*10 -> 2 ; W*y 4 -> 2 ; -> 4
+    return Xyzz9{X3, Y3, V, W};
+}
+// curve.cpp:340-396
+K16_HD Xyzz9 pdbl9(const Xyzz9& p)
+{
+    if (p.is_zero()) return p;
+    Fq9 U  = fdbl9(p.y);                            // 8
+    Fq9 V  = fsqr9(U);                              // 64 -> 2
+    Fq9 W  = fmul9(U, V);                           // 16 -> 2
+    Fq9 S  = fmul9(p.x, V);                         // 16 -> 2
+    Fq9 M  = fsqr9(p.x);                            // 64 -> 2
+    M      = fadd9(fdbl9(M), M);                    // 6
+    Fq9 X3 = fsub9<4>(fsqr9(M), fdbl9(S));          // < 6
+    Fq9 Y3 = fsub9<2>(fmul9(M, fsub9<8>(S, X3)), fmul9(W, p.y)); // 6*10 ; 2*4 ; -> 4
+    return Xyzz9{X3, Y3, fmul9(V, p.zz), fmul9(W, p.zzz)};
+}
+// curve.cpp:185-250
+K16_HD Xyzz9 padd_mixed9(const Xyzz9& p1, const Aff9& p2)
+{
+    if (p1.is_zero()) return Xyzz9::from_aff(p2);
+    if (p2.is_zero()) return p1;
+    Fq9 U2 = fmul9(p2.x, p1.zz);                    // 2*2 -> 2
+    Fq9 S2 = fmul9(p2.y, p1.zzz);                   // 2
+    Fq9 P  = fsub9<8>(U2, p1.x);                    // X1 < 8 -> P < 10
+    Fq9 R  = fsub9<4>(S2, p1.y);                    // Y1 < 4 -> R < 6
+    if (fq9_is_zero_mod_p<10>(P) && fq9_is_zero_mod_p<6>(R)) return pdbl_aff9(p2);
+    Fq9 PP  = fsqr9(P);                             // 100 -> 2
+    Fq9 PPP = fmul9(P, PP);                         // 20 -> 2
+    Fq9 Q   = fmul9(p1.x, PP);                      // 16 -> 2
+    Fq9 X3  = fsub9<4>(fsub9<2>(fsqr9(R), PPP), fdbl9(Q)); // 36 -> 2 ; -PPP -> 4 ; -2Q -> 8
+    Fq9 Y3  = fsub9<2>(fmul9(fsub9<8>(Q, X3), R), fmul9(p1.y, PPP)); // (Q - X3 + 8p) < 10 ; 10*6 -> 2 ; 4*2 -> 2 ; -> 4
+    return Xyzz9{X3, Y3, fmul9(p1.zz, PP), fmul9(p1.zzz, PPP)};
+}
+// curve.cpp:91-166
+K16_HD Xyzz9 padd9(const Xyzz9& p1, const Xyzz9& p2)
+{
+    if (p1.is_zero()) return p2;
+    if (p2.is_zero()) return p1;
+    Fq9 U1 = fmul9(p1.x, p2.zz);                    // 16 -> 2
+    Fq9 U2 = fmul9(p2.x, p1.zz);
+    Fq9 S1 = fmul9(p1.y, p2.zzz);                   // 8 -> 2
+    Fq9 S2 = fmul9(p2.y, p1.zzz);
+    Fq9 P  = fsub9<2>(U2, U1);                      // 4
+    Fq9 R  = fsub9<2>(S2, S1);                      // 4
+    if (fq9_is_zero_mod_p<4>(P) && fq9_is_zero_mod_p<4>(R)) return pdbl9(p1);
+    Fq9 PP  = fsqr9(P);                             // 16 -> 2
+    Fq9 PPP = fmul9(P, PP);
+    Fq9 Q   = fmul9(U1, PP);
+    Fq9 X3  = fsub9<4>(fsub9<2>(fsqr9(R), PPP), fdbl9(Q)); // 8
+    Fq9 Y3  = fsub9<2>(fmul9(fsub9<8>(Q, X3), R), fmul9(S1, PPP)); // 10*4 ; -> 4
+    return Xyzz9{X3, Y3, fmul9(fmul9(p1.zz, p2.zz), PP), fmul9(fmul9(p1.zzz, p2.zzz), PPP)};
+}
+
+// conversions of whole points
+K16_HD Aff9 aff9_from_canonical(const Aff<Fq>& a)
+{
+    return Aff9{fq9_from_fq(a.x), fq9_from_fq(a.y)}; // (0,0) -> exact zero limbs
+}
+K16_HD Xyzz<Fq> xyzz9_to_canonical(const Xyzz9& p)
+{
+    if (p.is_zero()) return Xyzz<Fq>::zero();
+    return Xyzz<Fq>{fq9_to_fq(p.x), fq9_to_fq(p.y), fq9_to_fq(p.zz), fq9_to_fq(p.zzz)};
+}
+K16_HD Xyzz9 xyzz9_from_canonical(const Xyzz<Fq>& p)
+{
+    if (p.is_zero()) return Xyzz9::zero();
+    return Xyzz9{fq9_from_fq(p.x), fq9_from_fq(p.y), fq9_from_fq(p.zz), fq9_from_fq(p.zzz)};
+}
+
+} // namespace k16

@@ -39,13 +39,13 @@ struct k16_ctx {
 
     // MSM workspace (grown on demand, reused across calls)
     k16_devbuf ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
-        ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan;
+        ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
     void* pinned = nullptr; // small pinned host staging buffer
     size_t pinned_bytes = 0;
 
     // state of the MSM currently enqueued (k16_msm_enqueue -> k16_msm_finish)
     int      pend_group = -1;
-    unsigned pend_c = 0, pend_w = 0;
+    unsigned pend_c = 0, pend_w = 0, pend_nbits = 0;
     uint64_t pend_n = 0;
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;

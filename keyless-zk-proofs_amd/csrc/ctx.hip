@@ -34,7 +34,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
         delete c;
         return K16_ERR_NO_DEVICE;
     }
-    c->pinned_bytes = 1 << 16;
+    c->pinned_bytes = 1 << 17;
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return K16_ERR_NO_DEVICE;
@@ -50,7 +50,7 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     k16_devbuf* bufs[] = {&c->ws_counts, &c->ws_offsets, &c->ws_cursor, &c->ws_sorted, &c->ws_segoff,
                           &c->ws_segbucket, &c->ws_partial, &c->ws_big, &c->ws_misc, &c->ws_lvl_a,
-                          &c->ws_lvl_b, &c->ws_lvl_c, &c->ws_lvl_d, &c->ws_scan};
+                          &c->ws_lvl_b, &c->ws_lvl_c, &c->ws_lvl_d, &c->ws_scan, &c->ws_conv};
     for (auto* b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto& kv : c->ntt_tables)

@@ -2,12 +2,15 @@
 // Kernels live in msm_kernels.inc, instantiated for G1 in msm_g1.hip and for G2 in msm_g2.hip.
 #include <string.h>
 #include <algorithm>
+#include <vector>
 #include "ctx.h"
+#include "bn254_fq9.h"
 
 using namespace k16;
 
-int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c);
-int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c);
+int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
+int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
+int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out);
 
 namespace {
 constexpr unsigned MAX_C = 16;
@@ -25,14 +28,23 @@ unsigned choose_c(const k16_ctx* ctx, uint64_t n)
     return (unsigned)c;
 }
 
+// Host tail of the MSM: per window  val = T[nbits] + M * sum_b 2^b T[b]  (see msm_kernels.inc, K4),
+// then the Horner combine over windows (multiexp.cpp:236-242).
 template <class F>
-void horner_host(const Xyzz<F>* win, unsigned W, unsigned c, Xyzz<F>* out)
+void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
 {
-    // multiexp.cpp:236-242
-    Xyzz<F> r = win[W - 1];
-    for (int j = (int)W - 2; j >= 0; j--) {
+    Xyzz<F> r = Xyzz<F>::zero();
+    for (int w = (int)W - 1; w >= 0; w--) {
+        const Xyzz<F>* tw = T + (size_t)w * (nbits + 1);
+        Xyzz<F>        t  = Xyzz<F>::zero();
+        for (int b = (int)nbits - 1; b >= 0; b--) {
+            t = pdbl(t);
+            t = padd(t, tw[b]);
+        }
+        for (unsigned k = 0; k < mlog; k++) t = pdbl(t);
+        t = padd(t, tw[nbits]);
         for (unsigned k = 0; k < c; k++) r = pdbl(r);
-        r = padd(r, win[j]);
+        r = padd(r, t);
     }
     *out = r;
 }
@@ -47,7 +59,7 @@ extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
     return K16_OK;
 }
 
-extern "C" int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n)
+static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, int prepared)
 {
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n >= (1ull << 32) / 64) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
@@ -60,8 +72,25 @@ extern "C" int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, con
     unsigned c  = choose_c(ctx, n);
     ctx->pend_c = c;
     ctx->pend_w = n_windows(c);
-    if (group == K16_G1) return k16_msm_enqueue_g1(ctx, d_bases, d_scalars, n, c);
-    return k16_msm_enqueue_g2(ctx, d_bases, d_scalars, n, c);
+    if (group == K16_G1) return k16_msm_enqueue_g1(ctx, d_bases, d_scalars, n, c, prepared);
+    return k16_msm_enqueue_g2(ctx, d_bases, d_scalars, n, c, prepared);
+}
+
+extern "C" int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n)
+{
+    return msm_enqueue_any(ctx, group, d_bases, d_scalars, n, 0);
+}
+extern "C" int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_prepared, const void* d_scalars,
+                                        uint64_t n)
+{
+    return msm_enqueue_any(ctx, group, d_prepared, d_scalars, n, 1);
+}
+extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out)
+{
+    if (!ctx || (group != K16_G1 && group != K16_G2) || (n && (!d_bases || !d_out))) return K16_ERR_ARG;
+    if (group == K16_G1) return k16_msm_prepare_g1(ctx, d_bases, n, d_out);
+    K16_HIP(ctx, hipMemcpyAsync(d_out, d_bases, (size_t)n * sizeof(G2Aff), hipMemcpyDeviceToDevice, ctx->stream));
+    return K16_OK;
 }
 
 extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
@@ -83,8 +112,17 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
     }
     K16_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (group == K16_G1) {
+        // the G1 kernels work in the radix-2^29 / R' domain: bring the few window/bit sums back to the
+        // reference's canonical Montgomery form first (exact conversion)
+        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 1);
+        std::vector<G1Xyzz> T(cnt);
+        for (unsigned i = 0; i < cnt; i++) {
+            Xyzz9 p9;
+            memcpy(&p9, (const char*)ctx->pinned + (size_t)i * sizeof(Xyzz9), sizeof p9);
+            T[i] = xyzz9_to_canonical(p9);
+        }
         G1Xyzz r;
-        horner_host<Fq>((const G1Xyzz*)ctx->pinned, ctx->pend_w, ctx->pend_c, &r);
+        horner_host<Fq>(T.data(), ctx->pend_w, ctx->pend_c, ctx->pend_nbits, 3, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G1Aff a = to_affine(r);
@@ -92,7 +130,7 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
         }
     } else {
         G2Xyzz r;
-        horner_host<Fq2>((const G2Xyzz*)ctx->pinned, ctx->pend_w, ctx->pend_c, &r);
+        horner_host<Fq2>((const G2Xyzz*)ctx->pinned, ctx->pend_w, ctx->pend_c, ctx->pend_nbits, 3, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G2Aff a = to_affine(r);

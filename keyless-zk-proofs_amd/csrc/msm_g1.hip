@@ -1,7 +1,24 @@
-// msm_g1.hip -- G1 (Fq) instantiation of the MSM kernels
+// msm_g1.hip -- G1 instantiation of the MSM kernels, on the radix-2^29 engine (bn254_fq9.h)
 #include <algorithm>
 #include "msm_kernels.inc"
-int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c)
+
+// zkey-format table (canonical Montgomery, 64 B/point) -> packed R'-domain rows the kernels gather from
+int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out)
 {
-    return msm_enqueue_t<k16::Fq>(ctx, (const k16::G1Aff*)d_bases, d_scalars, n, c);
+    if (n == 0) return K16_OK;
+    hipLaunchKernelGGL(k_convert_bases, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const k16::G1Aff*)d_bases, (k16::G1Aff*)d_out, n);
+    K16_HIP(ctx, hipGetLastError());
+    return K16_OK;
+}
+int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared)
+{
+    const k16::G1Aff* rows = (const k16::G1Aff*)d_bases;
+    if (!prepared) {
+        int rc = k16_ws_reserve(ctx, ctx->ws_conv, (size_t)n * sizeof(k16::G1Aff));
+        if (rc) return rc;
+        if ((rc = k16_msm_prepare_g1(ctx, d_bases, n, ctx->ws_conv.p))) return rc;
+        rows = (const k16::G1Aff*)ctx->ws_conv.p;
+    }
+    return msm_enqueue_t<Eng9>(ctx, rows, d_scalars, n, c);
 }

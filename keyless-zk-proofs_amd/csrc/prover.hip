@@ -192,6 +192,21 @@ int sample_blinding(uint8_t out[32])
     return K16_OK;
 }
 
+int msm_prepared(k16_ctx* ctx, int group, const void* d_rows, const void* d_scalars, uint64_t n, void* out_xyzz)
+{
+    int rc = k16_msm_enqueue_prepared(ctx, group, d_rows, d_scalars, n);
+    if (rc) return rc;
+    return k16_msm_finish(ctx, out_xyzz, nullptr);
+}
+
+// out-of-line host group operations (keeps the host compile of this file short)
+__attribute__((noinline)) G1Xyzz h_add(const G1Xyzz& a, const G1Xyzz& b) { return padd(a, b); }
+__attribute__((noinline)) G1Xyzz h_madd(const G1Xyzz& a, const G1Aff& b) { return padd_mixed(a, b); }
+__attribute__((noinline)) G1Xyzz h_mul(const G1Xyzz& a, const uint8_t* k) { return pmul_scalar(a, k); }
+__attribute__((noinline)) G2Xyzz h_add(const G2Xyzz& a, const G2Xyzz& b) { return padd(a, b); }
+__attribute__((noinline)) G2Xyzz h_madd(const G2Xyzz& a, const G2Aff& b) { return padd_mixed(a, b); }
+__attribute__((noinline)) G2Xyzz h_mul(const G2Xyzz& a, const uint8_t* k) { return pmul_scalar(a, k); }
+
 } // namespace
 
 struct k16_prover {
@@ -357,6 +372,14 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_wire, wire.data(), wire.size() * 4, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_coef, vals.data(), vals.size(), hipMemcpyHostToDevice, st), p);
+    // G1 tables -> the accumulate kernel's row layout, once (in place; see k16_msm_bases_prepare)
+    if ((rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_A, nv, p->d_A)) ||
+        (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_B1, nv, p->d_B1)) ||
+        (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_C, nc, p->d_C)) ||
+        (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_H, N, p->d_H))) {
+        prover_free(p);
+        return rc;
+    }
     K16_HIP_P(ctx, hipStreamSynchronize(st), p);
     // FFT table for 2 * domainSize (groth16.hpp:96)
     rc = k16_ntt_get_table(ctx, 2ull * N, &p->ntt);
@@ -436,11 +459,11 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     // groth16.cpp:88-112 : the four witness MSMs
     G1Xyzz pi_a, pib1, pi_c, pih;
     G2Xyzz pi_b;
-    if ((rc = k16_msm(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars, &pi_a, nullptr))) return rc;
-    if ((rc = k16_msm(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars, &pib1, nullptr))) return rc;
-    if ((rc = k16_msm(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars, &pi_b, nullptr))) return rc;
-    if ((rc = k16_msm(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1), (uint64_t)p->n_vars - p->n_public - 1,
-                      &pi_c, nullptr)))
+    if ((rc = msm_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars, &pi_a))) return rc;
+    if ((rc = msm_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars, &pib1))) return rc;
+    if ((rc = msm_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars, &pi_b))) return rc;
+    if ((rc = msm_prepared(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1), (uint64_t)p->n_vars - p->n_public - 1,
+                           &pi_c)))
         return rc;
 
     // groth16.cpp:116-275 : a, b, c and the H scalars
@@ -457,32 +480,32 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, st, p->d_a, p->d_b, p->d_c, N);
     K16_HIP(ctx, hipGetLastError());
     // groth16.cpp:281-283
-    if ((rc = k16_msm(ctx, K16_G1, p->d_H, p->d_a, N, &pih, nullptr))) return rc;
+    if ((rc = msm_prepared(ctx, K16_G1, p->d_H, p->d_a, N, &pih))) return rc;
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
 
     // groth16.cpp:325-352 : blinding (host; six single scalar multiplications)
     G1Xyzz d1 = G1Xyzz::from_aff(p->delta1);
-    pi_a      = padd_mixed(pi_a, p->alpha1);
-    pi_a      = padd(pi_a, pmul_scalar(d1, r_std));
+    pi_a      = h_madd(pi_a, p->alpha1);
+    pi_a      = h_add(pi_a, h_mul(d1, r_std));
 
-    pi_b = padd_mixed(pi_b, p->beta2);
-    pi_b = padd(pi_b, pmul_scalar(G2Xyzz::from_aff(p->delta2), s_std));
+    pi_b = h_madd(pi_b, p->beta2);
+    pi_b = h_add(pi_b, h_mul(G2Xyzz::from_aff(p->delta2), s_std));
 
-    pib1 = padd_mixed(pib1, p->beta1);
-    pib1 = padd(pib1, pmul_scalar(d1, s_std));
+    pib1 = h_madd(pib1, p->beta1);
+    pib1 = h_add(pib1, h_mul(d1, s_std));
 
-    pi_c = padd(pi_c, pih);
-    pi_c = padd(pi_c, pmul_scalar(pi_a, s_std));
-    pi_c = padd(pi_c, pmul_scalar(pib1, r_std));
+    pi_c = h_add(pi_c, pih);
+    pi_c = h_add(pi_c, h_mul(pi_a, s_std));
+    pi_c = h_add(pi_c, h_mul(pib1, r_std));
     Fr rr, ss;
     memcpy(rr.v, r_std, 32);
     memcpy(ss.v, s_std, 32);
     Fr      rs = to_mont(fmul(rr, ss)); // = r*s mod r in standard form (groth16.cpp:348-349)
     uint8_t rs_b[32];
     memcpy(rs_b, rs.v, 32);
-    pi_c = padd(pi_c, pneg(pmul_scalar(d1, rs_b)));
+    pi_c = h_add(pi_c, pneg(h_mul(d1, rs_b)));
 
     G1Aff A = to_affine(pi_a), Cc = to_affine(pi_c);
     G2Aff B = to_affine(pi_b);

@@ -1,0 +1,144 @@
+// tests/cpp/fq9_check.cpp -- host-side cross-check of the radix-2^29 field / G1 code (bn254_fq9.h)
+// against the canonical 8x32 implementation (bn254_field.h / bn254_curve.h), including the value
+// bounds the lazy reduction relies on.  Built and run by tests/test_fq9_host.py (no GPU needed: both
+// headers are __host__ __device__).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "bn254_curve.h"
+#include "bn254_fq9.h"
+using namespace k16;
+
+static uint64_t sm = 0x1234567;
+static uint64_t rnd()
+{
+    sm += 0x9E3779B97F4A7C15ull;
+    uint64_t z = sm;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static Fq rand_fq()
+{
+    Fq x;
+    for (int i = 0; i < 8; i += 2) {
+        uint64_t r = rnd();
+        x.v[i] = (uint32_t)r;
+        x.v[i + 1] = (uint32_t)(r >> 32);
+    }
+    x.v[7] &= 0x0fffffff; // < 2^252 < p
+    return x;
+}
+// v < K*p ?  (v normalised)
+static bool below_kp(const Fq9& v, int K)
+{
+    uint64_t kp[9], c = 0;
+    for (int i = 0; i < 9; i++) {
+        uint64_t t = (uint64_t)fq9c::P[i] * K + c;
+        if (i < 8) { kp[i] = t & fq9c::MASK; c = t >> 29; } else kp[i] = t;
+    }
+    for (int i = 8; i >= 0; i--) {
+        if (v.l[i] != kp[i]) return v.l[i] < kp[i];
+    }
+    return false;
+}
+static bool normalised(const Fq9& v)
+{
+    for (int i = 0; i < 8; i++) if (v.l[i] >> 29) return false;
+    return true;
+}
+static int fails = 0;
+#define CHECK(c, msg) do { if (!(c)) { fails++; if (fails < 20) printf("FAIL %s (line %d)\n", msg, __LINE__); } } while (0)
+
+static bool pt_bounds_ok(const Xyzz9& p)
+{
+    return normalised(p.x) && normalised(p.y) && normalised(p.zz) && normalised(p.zzz) && below_kp(p.x, 8) &&
+           below_kp(p.y, 4) && below_kp(p.zz, 2) && below_kp(p.zzz, 2);
+}
+static bool same_point_repr(const Xyzz9& a, const G1Xyzz& b)
+{
+    G1Xyzz c = xyzz9_to_canonical(a);
+    if (b.is_zero()) return a.is_zero();
+    return c.x == b.x && c.y == b.y && c.zz == b.zz && c.zzz == b.zzz;
+}
+
+int main()
+{
+    // field ops
+    for (int it = 0; it < 20000; it++) {
+        Fq a = rand_fq(), b = rand_fq();
+        if (it == 0) a = Fq::zero();
+        if (it == 1) { a = Fq::zero(); b = Fq::zero(); }
+        if (it == 2) a = Fq::one();
+        if (it == 3) { for (int i = 0; i < 8; i++) a.v[i] = FqParams::P[i]; a.v[0] -= 1; b = a; } // p-1
+        Fq9 A = fq9_from_fq(a), B = fq9_from_fq(b);
+        CHECK(normalised(A) && below_kp(A, 2), "from_fq bound");
+        CHECK(fq9_to_fq(A) == a, "roundtrip");
+        CHECK(fq9_to_fq(fmul9(A, B)) == fmul(a, b), "mul");
+        CHECK(fq9_to_fq(fadd9(A, B)) == fadd(a, b), "add");
+        CHECK(fq9_to_fq(fsub9<2>(A, B)) == fsub(a, b), "sub2");
+        CHECK(fq9_to_fq(fsub9<8>(A, B)) == fsub(a, b), "sub8");
+        Fq9 big = fadd9(fadd9(fadd9(A, B), fadd9(A, B)), fadd9(A, A)); // < 12p
+        CHECK(fq9_to_fq(fmul9(big, B)) == fmul(fadd(fadd(fadd(a, b), fadd(a, b)), fadd(a, a)), b), "mul with lazy operand");
+        CHECK(fq9_is_zero_mod_p<10>(fsub9<8>(A, A)), "x - x == 0 mod p");
+        CHECK(fq9_is_zero_mod_p<4>(A) == a.is_zero(), "is_zero");
+    }
+    // curve ops: random walks mixing madd / add / dbl with the exceptional cases
+    G1Aff g;
+    g.x = Fq::one();
+    g.y = fdbl(Fq::one());
+    const int NP = 64;
+    G1Aff tab[NP];
+    Aff9  tab9[NP];
+    {
+        G1Xyzz acc = G1Xyzz::zero();
+        for (int i = 0; i < NP; i++) {
+            acc     = padd_mixed(acc, g);
+            tab[i]  = to_affine(acc);
+            tab9[i] = aff9_from_canonical(tab[i]);
+        }
+        tab[7] = G1Aff{Fq::zero(), Fq::zero()}; // a (0,0) base
+        tab9[7] = aff9_from_canonical(tab[7]);
+        CHECK(tab9[7].is_zero(), "(0,0) converts to zero limbs");
+    }
+    for (int walk = 0; walk < 200; walk++) {
+        G1Xyzz c = G1Xyzz::zero(), c2 = G1Xyzz::zero();
+        Xyzz9  n = Xyzz9::zero(), n2 = Xyzz9::zero();
+        for (int step = 0; step < 60; step++) {
+            int op = (int)(rnd() % 8), k = (int)(rnd() % NP);
+            if (step == 1) { op = 0; k = 3; }
+            if (step == 2) { op = 0; k = 3; }               // maybe P + P
+            if (op <= 3) { c = padd_mixed(c, tab[k]); n = padd_mixed9(n, tab9[k]); }
+            else if (op == 4) { c = pdbl(c); n = pdbl9(n); }
+            else if (op == 5) { c2 = padd(c2, c); n2 = padd9(n2, n); }
+            else if (op == 6) { c = padd(c, c2); n = padd9(n, n2); }
+            else { // P + (-P) and P + P through the projective add
+                G1Xyzz neg = pneg(c);
+                Xyzz9  neg9 = xyzz9_from_canonical(neg);
+                G1Xyzz z = padd(c, neg);
+                Xyzz9  z9 = padd9(n, neg9);
+                CHECK(z.is_zero() && z9.is_zero(), "P + (-P)");
+                c = padd(c, c); n = padd9(n, n);
+            }
+            CHECK(pt_bounds_ok(n) && pt_bounds_ok(n2), "point bounds");
+            CHECK(same_point_repr(n, c), "XYZZ representation equal after canonicalisation");
+            CHECK(same_point_repr(n2, c2), "XYZZ (second accumulator)");
+        }
+    }
+    // acc == table point -> doubling branch of the mixed add; acc == -table point -> infinity
+    for (int k = 0; k < NP; k++) {
+        if (k == 7) continue;
+        G1Xyzz c = G1Xyzz::from_aff(tab[k]);
+        Xyzz9  n = Xyzz9::from_aff(tab9[k]);
+        CHECK(same_point_repr(padd_mixed9(n, tab9[k]), padd_mixed(c, tab[k])), "madd P+P");
+        G1Aff  ng = pneg(tab[k]);
+        Aff9   ng9 = aff9_from_canonical(ng);
+        CHECK(padd_mixed9(n, ng9).is_zero() && padd_mixed(c, ng).is_zero(), "madd P+(-P)");
+        // same with a non-trivial zz
+        G1Xyzz c3 = padd_mixed(padd_mixed(c, tab[(k + 1) % NP == 7 ? 8 : (k + 1) % NP]), pneg(tab[(k + 1) % NP == 7 ? 8 : (k + 1) % NP]));
+        Xyzz9  n3 = xyzz9_from_canonical(c3);
+        CHECK(same_point_repr(padd_mixed9(n3, tab9[k]), padd_mixed(c3, tab[k])), "madd P+P (zz != 1)");
+    }
+    printf(fails ? "FAILED %d checks\n" : "OK\n", fails);
+    return fails ? 1 : 0;
+}

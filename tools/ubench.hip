@@ -59,6 +59,47 @@ __global__ void __launch_bounds__(128) k_madd_chain(G1Xyzz* out, const G1Aff* in
     out[tid & 1023] = acc;
 }
 
+// ---- radix-2^29 (9 limbs) Montgomery multiply feasibility: 64-bit column accumulators, no carries
+struct F29 { uint32_t l[9]; };
+__device__ __constant__ uint32_t P29[9];
+__device__ __forceinline__ F29 fmul29(const F29& a, const F29& b, uint32_t np29)
+{
+    const uint32_t MASK = (1u << 29) - 1;
+    uint32_t m[9];
+    F29      r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc2 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j < 0 || j > 8) continue;
+            acc += (uint64_t)a.l[i] * b.l[j];
+            if (k < 9) { if (i < k) acc2 += (uint64_t)m[i] * P29[j]; }
+            else acc2 += (uint64_t)m[i] * P29[j];
+        }
+        acc += acc2;
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * np29) & MASK;
+            acc += (uint64_t)m[k] * P29[0];
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+__global__ void __launch_bounds__(256) k_fmul29_chain(F29* out, const F29* in, int iters, uint32_t np29)
+{
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    F29 x = in[tid & 1023], y = in[(tid + 7) & 1023];
+    for (int i = 0; i < iters; i++) { x = fmul29(x, y, np29); y = fmul29(y, x, np29); }
+    out[tid & 1023] = x;
+}
+
 template <class K, class... A>
 float timeit(dim3 g, dim3 b, K k, A... a)
 {
@@ -102,6 +143,29 @@ int main()
         float m1 = timeit(g, b, k_fmul_chain<1>, out, (const Fq*)in, iters);
         double nm = (double)256 * bpc * 256 * iters * 2;
         printf("fmul chain  %d blk/CU: %.3f ms -> %.1f G modmul/s ; add/sub chain %.3f ms -> %.1f G/s\n", bpc, m0, nm / m0 / 1e6, m1, nm / m1 / 1e6);
+    }
+    {
+        // p in radix 2^29
+        unsigned __int128 dummy = 0; (void)dummy;
+        uint32_t p32[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        uint32_t p29[9];
+        for (int i = 0; i < 9; i++) {
+            int bit = 29 * i; uint64_t v = 0;
+            for (int w = 0; w < 8; w++) { int off = 32 * w - bit; if (off > -32 && off < 29) v |= off >= 0 ? ((uint64_t)p32[w] << off) : ((uint64_t)p32[w] >> (-off)); }
+            p29[i] = (uint32_t)(v & ((1u << 29) - 1));
+        }
+        hipMemcpyToSymbol(HIP_SYMBOL(P29), p29, sizeof p29);
+        uint32_t inv = 1; for (int i = 0; i < 6; i++) inv *= 2 - p29[0] * inv;
+        uint32_t np29 = (0u - inv) & ((1u << 29) - 1);
+        F29* in29; F29* out29; hipMalloc(&in29, 1024 * sizeof(F29)); hipMalloc(&out29, 1024 * sizeof(F29));
+        hipMemset(in29, 0x05, 1024 * sizeof(F29));
+        for (int bpc = 1; bpc <= 8; bpc *= 2) {
+            dim3 g(256 * bpc), b(256);
+            int iters = 512;
+            float m0 = timeit(g, b, k_fmul29_chain, out29, (const F29*)in29, iters, np29);
+            double nm = (double)256 * bpc * 256 * iters * 2;
+            printf("fmul29 chain %d blk/CU: %.3f ms -> %.1f G modmul/s\n", bpc, m0, nm / m0 / 1e6);
+        }
     }
     for (int bpc = 1; bpc <= 8; bpc *= 2) {
         dim3 g(256 * bpc), b(128);
