@@ -225,3 +225,26 @@ def test_toy_proof_bit_exact(ctx, toy_paths):
     assert bp.verify_json(vk, js, [2])
     assert js != p.prove_file(wtns)
     p.close()
+
+
+@pytest.mark.parametrize("shape", [(3000, 2, 4096, 9000), (40000, 1, 1 << 16, 150000)])
+def test_synthetic_circuit_proof_bit_exact(ctx, tmp_path, shape):
+    """Non-toy prove(): random circuit of the given (nVars, nPublic, domainSize, nCoefs); the HIP proof JSON and
+    the H scalars must equal the oracle's byte for byte (same witness, same injected r, s)."""
+    import k16
+    import zkey_builder as zb
+    n_vars, n_pub, N, n_coefs = shape
+    zk, wt = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    zb.build_zkey(zk, n_vars, n_pub, N, n_coefs, seed=11)
+    w = zb.build_wtns(wt, n_vars, seed=12)
+    r, s = pm.limbs(pm.SplitMix64(77).below(pm.R)), pm.limbs(pm.SplitMix64(78).below(pm.R))
+    p = k16.Prover(ctx, zk)
+    assert p.info() == dict(n_vars=n_vars, n_public=n_pub, domain_size=N, n_coefs=n_coefs)
+    got = p.prove_file(wt, r, s)
+    h_gpu = p.last_h()
+    want, h_ref = ol.prove_files(zk, wt, r, s, nthreads=8, want_h=True)
+    assert np.array_equal(h_gpu, h_ref)
+    assert got == want
+    # witness handed over in memory (SURVEY 8(f).1) gives the same proof
+    assert p.prove_mem(w, r, s) == want
+    p.close()

@@ -52,3 +52,46 @@ def test_threads_do_not_change_the_proof(toy_paths):
     zkey, wtns, _ = toy_paths
     r, s = pm.limbs(12345), pm.limbs(pm.R - 1)
     assert ol.prove_files(zkey, wtns, r, s, nthreads=1) == ol.prove_files(zkey, wtns, r, s, nthreads=4)
+
+
+def test_synthetic_circuit_h_scalars_against_python_model(tmp_path):
+    """Pins the SpMV -> a*b -> 3 x (iNTT, coset shift, NTT) -> a*b - c chain (groth16.cpp:116-275) of the
+    oracle on a small random circuit against an independent big-int evaluation:
+    h[i] = (A.w)(x_i) * (B.w)(x_i) - ((A.w)*(B.w) on the domain)(x_i) at the coset points x_i = g_{2N}^(2i+1)."""
+    import numpy as np
+    import zkey_builder as zb
+    n_vars, n_pub, N, n_coefs = 40, 2, 16, 70
+    zk, wt = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    zb.build_zkey(zk, n_vars, n_pub, N, n_coefs, seed=3)
+    w = zb.build_wtns(wt, n_vars, seed=4)
+    _, h = ol.prove_files(zk, wt, want_h=True)
+    got = [sum(int(h[i, k]) << (64 * k) for k in range(4)) for i in range(N)]
+    # model
+    import struct
+    data = open(zk, "rb").read()
+    # locate section 4
+    pos, secs = 12, {}
+    for _ in range(struct.unpack_from("<I", data, 8)[0]):
+        t, sz = struct.unpack_from("<IQ", data, pos)
+        secs[t] = (pos + 12, sz)
+        pos += 12 + sz
+    o, sz = secs[4]
+    nc = struct.unpack_from("<I", data, o)[0]
+    wv = [pm.unlimbs(bytes(w[i])) for i in range(n_vars)]
+    a, b = [0] * N, [0] * N
+    rinv2 = pow(pm.MONT, -2, pm.R)
+    for i in range(nc):
+        m, c, s = struct.unpack_from("<III", data, o + 4 + 44 * i)
+        val = pm.unlimbs(data[o + 4 + 44 * i + 12:o + 4 + 44 * i + 44]) * rinv2 % pm.R
+        (a if m == 0 else b)[c] = ((a if m == 0 else b)[c] + wv[s] * val) % pm.R
+    cc = [x * y % pm.R for x, y in zip(a, b)]
+    lg = 4
+    g2n = pm.root_of_unity(lg + 1)
+
+    def to_coset(ev):
+        co = pm.intt_naive(ev, lg)
+        co = [v * pow(g2n, i, pm.R) % pm.R for i, v in enumerate(co)]
+        return pm.ntt_naive(co, lg)
+    A, B, C = to_coset(a), to_coset(b), to_coset(cc)
+    want = [(x * y - z) % pm.R for x, y, z in zip(A, B, C)]
+    assert got == want
