@@ -48,6 +48,13 @@ struct k16_ctx {
     unsigned pend_c = 0, pend_w = 0, pend_nbits = 0;
     uint64_t pend_n = 0;
 
+    // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2
+    // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)
+    const void* sorted_scalars = nullptr;
+    uint64_t    sorted_n = 0;
+    unsigned    sorted_c = 0;
+    bool        reuse_sort = false;
+
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };
 
@@ -62,24 +69,25 @@ struct k16_ctx {
 
 int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes);
 
-void k16_stats_begin(k16_ctx* ctx, const char* name);
-void k16_stats_end(k16_ctx* ctx);
+void k16_stats_begin(k16_ctx* ctx, const char* name, hipStream_t st);
+void k16_stats_end(k16_ctx* ctx, hipStream_t st);
 int  k16_stats_resolve(k16_ctx* ctx);
 
 // brackets a group of launches with a HIP event pair on the context's stream (no host sync)
 struct k16_stat_scope {
-    k16_ctx* ctx;
-    bool     on;
-    k16_stat_scope(k16_ctx* c, const char* n) : ctx(c), on(c->stats_on)
+    k16_ctx*    ctx;
+    bool        on;
+    hipStream_t st;
+    k16_stat_scope(k16_ctx* c, const char* n, hipStream_t s = nullptr) : ctx(c), on(c->stats_on), st(s ? s : c->stream)
     {
-        if (on) k16_stats_begin(ctx, n);
+        if (on) k16_stats_begin(ctx, n, st);
     }
     ~k16_stat_scope()
     {
-        if (on) k16_stats_end(ctx);
+        if (on) k16_stats_end(ctx, st);
     }
 };
 
 // host-side helpers implemented in msm.hip
 int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out);
-int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse);
+int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st);

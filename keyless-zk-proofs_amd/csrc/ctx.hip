@@ -114,7 +114,7 @@ extern "C" int k16_timer_stop(k16_ctx* c, float* ms)
     K16_HIP(c, hipEventElapsedTime(ms, c->ev_a, c->ev_b));
     return K16_OK;
 }
-void k16_stats_begin(k16_ctx* c, const char* name)
+void k16_stats_begin(k16_ctx* c, const char* name, hipStream_t st)
 {
     if (c->ks_used + 2 > c->ks_pool.size()) {
         for (int i = 0; i < 64; i++) {
@@ -124,18 +124,18 @@ void k16_stats_begin(k16_ctx* c, const char* name)
         }
     }
     c->ks_pending.emplace_back(name, c->ks_used);
-    (void)hipEventRecord(c->ks_pool[c->ks_used], c->stream);
+    (void)hipEventRecord(c->ks_pool[c->ks_used], st);
     c->ks_used += 2;
 }
-void k16_stats_end(k16_ctx* c)
+void k16_stats_end(k16_ctx* c, hipStream_t st)
 {
     if (c->ks_pending.empty()) return;
-    (void)hipEventRecord(c->ks_pool[c->ks_pending.back().second + 1], c->stream);
+    (void)hipEventRecord(c->ks_pool[c->ks_pending.back().second + 1], st);
 }
 int k16_stats_resolve(k16_ctx* c)
 {
     if (c->ks_pending.empty()) return K16_OK;
-    K16_HIP(c, hipStreamSynchronize(c->stream));
+    K16_HIP(c, hipDeviceSynchronize());
     for (auto& pr : c->ks_pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ks_pool[pr.second], c->ks_pool[pr.second + 1]) == hipSuccess) {

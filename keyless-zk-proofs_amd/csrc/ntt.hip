@@ -147,25 +147,26 @@ int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out)
     return K16_OK;
 }
 
-int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse)
+int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st)
 {
+    if (!st) st = ctx->stream;
     if (n == 0 || (n & (n - 1)) || n > (1ull << tab->s)) {
         ctx->err = "ntt: n must be a power of two <= table size";
         return K16_ERR_ARG;
     }
     uint32_t       logn = ilog2_u64(n);
-    k16_stat_scope ss(ctx, "ntt");
+    k16_stat_scope ss(ctx, "ntt", st);
     if (logn >= 1) {
-        hipLaunchKernelGGL(k_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_a, logn);
+        hipLaunchKernelGGL(k_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, logn);
         for (uint32_t s = 1; s <= logn; s++)
-            hipLaunchKernelGGL(k_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, ctx->stream, d_a,
+            hipLaunchKernelGGL(k_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, d_a,
                                tab->roots, logn, s, tab->s);
     }
     if (inverse) {
         if (logn == 0) {
             // n == 1: fft.cpp:243-244 scales a[0] twice (a[0] and a[n>>1] alias) by 2^0 = 1: identity
         } else {
-            hipLaunchKernelGGL(k_inv_tail, dim3((unsigned)((n / 2 + 1 + 255) / 256)), dim3(256), 0, ctx->stream, d_a,
+            hipLaunchKernelGGL(k_inv_tail, dim3((unsigned)((n / 2 + 1 + 255) / 256)), dim3(256), 0, st, d_a,
                                logn, tab->pow2inv[logn]);
         }
     }
@@ -179,7 +180,7 @@ extern "C" int k16_ntt(k16_ctx* ctx, void* d_a, uint64_t n, uint64_t max_domain,
     k16_ntt_table* tab = nullptr;
     int            rc  = k16_ntt_get_table(ctx, max_domain, &tab);
     if (rc) return rc;
-    return k16_ntt_enqueue(ctx, (Fr*)d_a, n, tab, inverse);
+    return k16_ntt_enqueue(ctx, (Fr*)d_a, n, tab, inverse, nullptr);
 }
 
 extern "C" int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_domain, int inverse)

@@ -223,6 +223,8 @@ struct k16_prover {
     // per-proof buffers
     Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
     k16_ntt_table* ntt = nullptr;
+    hipStream_t    st2 = nullptr;          // polynomial chain (SpMV, NTTs) runs beside the witness MSMs
+    hipEvent_t     ev_w = nullptr, ev_h = nullptr;
     std::vector<uint8_t> last_h;
 };
 
@@ -233,6 +235,9 @@ static void prover_free(k16_prover* p)
                     p->d_wtns, p->d_a, p->d_b, p->d_c};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (p->st2) (void)hipStreamDestroy(p->st2);
+    if (p->ev_w) (void)hipEventDestroy(p->ev_w);
+    if (p->ev_h) (void)hipEventDestroy(p->ev_h);
     delete p;
 }
 
@@ -388,6 +393,9 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         return rc;
     }
     K16_HIP_P(ctx, hipStreamSynchronize(st), p);
+    K16_HIP_P(ctx, hipStreamCreateWithFlags(&p->st2, hipStreamNonBlocking), p);
+    K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_w, hipEventDisableTiming), p);
+    K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming), p);
     *out = p;
     return K16_OK;
 }
@@ -456,30 +464,40 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
 
-    // groth16.cpp:88-112 : the four witness MSMs
+    // The reference overlaps the four witness MSMs with the a/b/c chain through std::async
+    // (groth16.cpp:88-112 vs :116-275); here the chain (HBM-bound) runs on a second stream beside the
+    // MSMs (integer-issue-bound) and is joined before the H MSM.
+    hipStream_t s2 = p->st2;
+    K16_HIP(ctx, hipEventRecord(p->ev_w, st));
+    K16_HIP(ctx, hipStreamWaitEvent(s2, p->ev_w, 0));
+    const unsigned gN = (N + 255) / 256;
+    hipLaunchKernelGGL(k_spmv, dim3((2 * N + 255) / 256), dim3(256), 0, s2, p->d_rowptr, p->d_wire, p->d_coef,
+                       p->d_wtns, p->d_a, p->d_b, N);
+    hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N);
+    Fr* vec[3] = {p->d_a, p->d_b, p->d_c};
+    for (int k = 0; k < 3; k++) {
+        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 1, s2))) return rc;
+        hipLaunchKernelGGL(k_shift, dim3(gN), dim3(256), 0, s2, vec[k], p->ntt->roots, N, p->ntt->s - p->logN - 1);
+        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 0, s2))) return rc;
+    }
+    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_b, p->d_c, N);
+    K16_HIP(ctx, hipGetLastError());
+    K16_HIP(ctx, hipEventRecord(p->ev_h, s2));
+
+    // groth16.cpp:88-112 : the four witness MSMs.  A, B1 and B2 share their scalars (the witness), so the
+    // bucket sort of the A MSM is reused for B1 and B2.
     G1Xyzz pi_a, pib1, pi_c, pih;
     G2Xyzz pi_b;
     if ((rc = msm_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars, &pi_a))) return rc;
+    ctx->reuse_sort = true;
     if ((rc = msm_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars, &pib1))) return rc;
+    ctx->reuse_sort = true;
     if ((rc = msm_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars, &pi_b))) return rc;
     if ((rc = msm_prepared(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1), (uint64_t)p->n_vars - p->n_public - 1,
                            &pi_c)))
         return rc;
-
-    // groth16.cpp:116-275 : a, b, c and the H scalars
-    const unsigned gN = (N + 255) / 256;
-    hipLaunchKernelGGL(k_spmv, dim3((2 * N + 255) / 256), dim3(256), 0, st, p->d_rowptr, p->d_wire, p->d_coef,
-                       p->d_wtns, p->d_a, p->d_b, N);
-    hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, st, p->d_c, p->d_a, p->d_b, N);
-    Fr* vec[3] = {p->d_a, p->d_b, p->d_c};
-    for (int k = 0; k < 3; k++) {
-        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 1))) return rc;
-        hipLaunchKernelGGL(k_shift, dim3(gN), dim3(256), 0, st, vec[k], p->ntt->roots, N, p->ntt->s - p->logN - 1);
-        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 0))) return rc;
-    }
-    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, st, p->d_a, p->d_b, p->d_c, N);
-    K16_HIP(ctx, hipGetLastError());
     // groth16.cpp:281-283
+    K16_HIP(ctx, hipStreamWaitEvent(st, p->ev_h, 0));
     if ((rc = msm_prepared(ctx, K16_G1, p->d_H, p->d_a, N, &pih))) return rc;
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));

@@ -1,0 +1,140 @@
+"""Full Groth16 proof on one MI355X at Keyless shape (BASELINE config 3) with a SYNTHETIC key:
+nVars = 1,343,588, nPublic = 1, domainSize = 2^21, nCoefs ~ 8.3 M; the real Keyless zkey is
+not available offline.  Reports proofs/s, p50 latency and the device-time split.  --check also runs the CPU
+oracle once on the same files and compares the proof JSON byte for byte (minutes of CPU time).
+
+    python tools/bench_proof.py [--scale 1.0] [--proofs 10] [--check]
+"""
+import argparse
+import json
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "keyless-zk-proofs_amd"))
+import k16  # noqa: E402
+
+Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+
+
+def le32(x):
+    return x.to_bytes(32, "little")
+
+
+def section(t, payload):
+    return struct.pack("<IQ", t, len(payload)) + payload
+
+
+def synth_zkey_bytes(ctx, n_vars, n_public, N, n_coefs, seed=1):
+    rs = np.random.RandomState(seed)
+
+    def pts(group, start, n, zero_frac=0.0):
+        d = ctx.synth_points(group, start, n)
+        a = d.download(np.uint8, (n, k16.AFF_BYTES[group])).copy()
+        d.free()
+        if zero_frac > 0:
+            a[rs.rand(n) < zero_frac] = 0
+        return a.tobytes()
+
+    g1 = pts(k16.G1, 100, 3)
+    g2 = pts(k16.G2, 50, 3)
+    hdr = struct.pack("<I", 32) + le32(Q) + struct.pack("<I", 32) + le32(R) + struct.pack("<III", n_vars, n_public, N)
+    hdr += g1[0:64] + g1[64:128] + g2[0:128] + g2[128:256] + g1[128:192] + g2[256:384]
+    # coefficients: snarkjs order (by constraint, then matrix); values = small ints * R^2 mod r
+    coef = np.zeros(n_coefs, dtype=[("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "V32")])
+    coef["m"] = rs.randint(0, 2, size=n_coefs)
+    coef["c"] = np.sort(rs.randint(0, N, size=n_coefs))
+    coef["s"] = rs.randint(0, n_vars, size=n_coefs)
+    r2 = pow(1 << 256, 2, R)
+    table = np.frombuffer(b"".join(le32(v * r2 % R) for v in range(1, 257)), dtype="V32")
+    coef["v"] = table[rs.randint(0, 256, size=n_coefs)]
+    secs = [section(1, struct.pack("<I", 1)), section(2, hdr),
+            section(4, struct.pack("<I", n_coefs) + coef.tobytes()),
+            section(5, pts(k16.G1, 1000, n_vars)),
+            section(6, pts(k16.G1, 3000000, n_vars, 0.5)),
+            section(7, pts(k16.G2, 5000, n_vars, 0.5)),
+            section(8, pts(k16.G1, 6000000, n_vars - n_public - 1)),
+            section(9, pts(k16.G1, 9000000, N))]
+    return b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(secs)
+
+
+def synth_witness(n_vars, seed):
+    rs = np.random.RandomState(seed)
+    w = np.zeros((n_vars, 32), dtype=np.uint8)
+    u = rs.rand(n_vars)
+    bits = u < 0.90
+    w[bits, 0] = rs.randint(0, 2, size=int(bits.sum()))
+    byts = (u >= 0.90) & (u < 0.98)
+    w[byts, 0] = rs.randint(0, 256, size=int(byts.sum()))
+    full = u >= 0.98
+    f = rs.randint(0, 256, size=(int(full.sum()), 32), dtype=np.uint8)
+    f[:, 31] &= 0x1F
+    w[full] = f
+    w[0] = 0
+    w[0, 0] = 1
+    return w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the circuit (1.0 = Keyless shape)")
+    ap.add_argument("--proofs", type=int, default=10)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    n_vars = max(int(1343588 * args.scale), 8)
+    N = 1 << max(int(np.ceil(np.log2(max(1376867 * args.scale, 4)))), 2)
+    n_coefs = int(8300000 * args.scale)
+    ctx = k16.Context(0)
+    t0 = time.time()
+    zk = synth_zkey_bytes(ctx, n_vars, 1, N, n_coefs)
+    print("synthetic zkey: nVars=%d N=2^%d nCoefs=%d  %.0f MB  (%.1f s)" % (n_vars, int(np.log2(N)), n_coefs, len(zk) / 1e6, time.time() - t0), flush=True)
+    zpath = "/tmp/k16_synth.zkey"
+    with open(zpath, "wb") as f:
+        f.write(zk)
+    del zk
+    t0 = time.time()
+    prover = k16.Prover(ctx, zpath)
+    print("prover create (parse + CSR + upload + table prepare + roots): %.2f s" % (time.time() - t0), flush=True)
+    r, s = le32(12345678901234567890 % R), le32(98765432109876543210 % R)
+    wits = [synth_witness(n_vars, 100 + i) for i in range(min(args.proofs, 4))]
+    prover.prove_mem(wits[0], r, s)  # warm-up: workspace allocation
+    lat, dev = [], []
+    ctx.stats_enable(True)
+    ctx.stats_reset()
+    t_all = time.perf_counter()
+    for i in range(args.proofs):
+        t1 = time.perf_counter()
+        js = prover.prove_mem(wits[i % len(wits)], r, s)
+        lat.append((time.perf_counter() - t1) * 1e3)
+        dev.append(prover.last_device_ms)
+    total = time.perf_counter() - t_all
+    stages = {k: ctx.stats_get(k)[1] / args.proofs for k in ("msm_sort", "msm_accumulate", "msm_fold", "msm_reduce", "ntt")}
+    ctx.stats_enable(False)
+    out = {"metric": "Groth16 proofs/s (synthetic Keyless-shape key, 1 MI355X)", "value": args.proofs / total,
+           "p50_ms": float(np.median(lat)), "p99_ms": float(np.percentile(lat, 99)), "device_ms_p50": float(np.median(dev)),
+           "stage_ms_per_proof": stages, "n_vars": n_vars, "domain": N, "n_coefs": n_coefs}
+    print(json.dumps(out), flush=True)
+    if args.check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as ol
+        wpath = "/tmp/k16_synth.wtns"
+        sec1 = struct.pack("<I", 32) + le32(R) + struct.pack("<I", n_vars)
+        with open(wpath, "wb") as f:
+            f.write(b"wtns" + struct.pack("<II", 2, 2) + section(1, sec1) + section(2, wits[0].tobytes()))
+        t0 = time.time()
+        want = ol.prove_files(zpath, wpath, r, s, nthreads=min(os.cpu_count() or 1, 16))
+        cpu_s = time.time() - t0
+        got = prover.prove_mem(wits[0], r, s)
+        print(json.dumps({"check": "proof JSON equal to CPU oracle", "equal": got == want, "oracle_seconds": cpu_s}), flush=True)
+        assert got == want
+    prover.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
