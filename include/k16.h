@@ -91,7 +91,7 @@ int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_
 int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine);
 /* Static point tables (the zkey's sections 5-9) can be prepared once: d_out (same size as d_bases)
  * receives the rows in the layout the accumulate kernel gathers from (G1: x*2^261, y*2^261 mod p packed
- * in 2 x 32 B -- the Montgomery form of the kernels' radix-2^29 field; G2: unchanged).  A prepared
+ * in 2 x 32 B -- the Montgomery form of the kernels' radix-2^29 field; G2: the same per Fq2 component).  A prepared
  * table is passed to k16_msm_enqueue_prepared instead of the zkey-format one. */
 int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out);
 int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_prepared, const void* d_scalars, uint64_t n);

@@ -331,4 +331,61 @@ K16_HD Xyzz9 xyzz9_from_canonical(const Xyzz<Fq>& p)
     return Xyzz9{fq9_from_fq(p.x), fq9_from_fq(p.y), fq9_from_fq(p.zz), fq9_from_fq(p.zzz)};
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2+1) over Fq9, with the simple invariant "every component < 2p (+ 2^-17 p)".
+// Each operation ends in fred9, a partial reduction by a quotient estimated from the top limb
+// (value / 2^232 against p / 2^232 = 3171406.3): one 9-limb multiply-subtract, ~15 % of a multiply.
+// With the invariant in place the generic XYZZ formulas of bn254_curve.h apply unchanged (G2).
+// ------------------------------------------------------------------------------------------------
+// v < 16p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17))
+K16_HD Fq9 fred9(const Fq9& v)
+{
+    const uint32_t t = v.l[8];
+    uint32_t       q = (uint32_t)(((uint64_t)t * 5547123ull) >> 44); // floor(t / 3171407) or one less
+    q += ((q + 1) * 3171407u <= t) ? 1u : 0u;
+    Fq9     r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        int64_t x = (int64_t)v.l[i] - (int64_t)((uint64_t)q * fq9c::P[i]) + c;
+        if (i < 8) {
+            r.l[i] = (uint32_t)x & fq9c::MASK;
+            c      = x >> 29;
+        } else {
+            r.l[8] = (uint32_t)x;
+        }
+    }
+    return r;
+}
+
+struct Fq2n {
+    Fq9 a, b;
+    static K16_HD Fq2n zero() { return Fq2n{fq9_zero(), fq9_zero()}; }
+    static K16_HD Fq2n one() { return Fq2n{fq9_one(), fq9_zero()}; }
+    K16_HD bool        is_zero() const { return fq9_is_zero_mod_p<3>(a) && fq9_is_zero_mod_p<3>(b); }
+};
+K16_HD Fq2n fadd(const Fq2n& x, const Fq2n& y) { return Fq2n{fred9(fadd9(x.a, y.a)), fred9(fadd9(x.b, y.b))}; }
+K16_HD Fq2n fsub(const Fq2n& x, const Fq2n& y) { return Fq2n{fred9(fsub9<4>(x.a, y.a)), fred9(fsub9<4>(x.b, y.b))}; } // 4p offset: slack for the 2p+eps invariant
+K16_HD Fq2n fdbl(const Fq2n& x) { return Fq2n{fred9(fdbl9(x.a)), fred9(fdbl9(x.b))}; }
+K16_HD Fq2n fneg(const Fq2n& x) { return fsub(Fq2n::zero(), x); }
+// f2field.cpp:122-142 (Karatsuba, non-residue -1): sums < 4p each, 4*4 = 16 <= 128
+K16_HD Fq2n fmul(const Fq2n& x, const Fq2n& y)
+{
+    Fq9 aa = fmul9(x.a, y.a);
+    Fq9 bb = fmul9(x.b, y.b);
+    Fq9 s  = fmul9(fadd9(x.a, x.b), fadd9(y.a, y.b));
+    return Fq2n{fred9(fsub9<4>(aa, bb)), fred9(fsub9<4>(fsub9<4>(s, aa), bb))}; // < 6p and < 10p before fred9 (valid to 16p)
+}
+// f2field.cpp:144-158 (complex squaring)
+K16_HD Fq2n fsqr(const Fq2n& x)
+{
+    Fq9 ab = fmul9(x.a, x.b);
+    Fq9 ra = fmul9(fadd9(x.a, x.b), fsub9<4>(x.a, x.b)); // 4 * 6 = 24
+    return Fq2n{ra, fred9(fdbl9(ab))};
+}
+
+K16_HD Fq2n fq2n_from_canonical(const Fq2& x) { return Fq2n{fq9_from_fq(x.a), fq9_from_fq(x.b)}; }
+K16_HD Fq2  fq2n_to_canonical(const Fq2n& x) { return Fq2{fq9_to_fq(x.a), fq9_to_fq(x.b)}; }
+
 } // namespace k16

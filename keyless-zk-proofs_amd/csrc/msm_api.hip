@@ -11,6 +11,7 @@ using namespace k16;
 int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
 int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
 int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out);
+int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out);
 
 namespace {
 constexpr unsigned MAX_C = 16;
@@ -89,8 +90,7 @@ extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_base
 {
     if (!ctx || (group != K16_G1 && group != K16_G2) || (n && (!d_bases || !d_out))) return K16_ERR_ARG;
     if (group == K16_G1) return k16_msm_prepare_g1(ctx, d_bases, n, d_out);
-    K16_HIP(ctx, hipMemcpyAsync(d_out, d_bases, (size_t)n * sizeof(G2Aff), hipMemcpyDeviceToDevice, ctx->stream));
-    return K16_OK;
+    return k16_msm_prepare_g2(ctx, d_bases, n, d_out);
 }
 
 extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
@@ -129,8 +129,17 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
             memcpy(h_out_affine, &a, sizeof a);
         }
     } else {
+        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 1);
+        std::vector<G2Xyzz> T(cnt);
+        for (unsigned i = 0; i < cnt; i++) {
+            Xyzz<Fq2n> p9;
+            memcpy(&p9, (const char*)ctx->pinned + (size_t)i * sizeof p9, sizeof p9);
+            T[i] = p9.is_zero() ? G2Xyzz::zero()
+                                : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
+                                         fq2n_to_canonical(p9.zzz)};
+        }
         G2Xyzz r;
-        horner_host<Fq2>((const G2Xyzz*)ctx->pinned, ctx->pend_w, ctx->pend_c, ctx->pend_nbits, 3, &r);
+        horner_host<Fq2>(T.data(), ctx->pend_w, ctx->pend_c, ctx->pend_nbits, 3, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G2Aff a = to_affine(r);

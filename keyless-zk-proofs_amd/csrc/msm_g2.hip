@@ -1,8 +1,23 @@
-// msm_g2.hip -- G2 (Fq2) instantiation of the MSM kernels, canonical 8x32-bit field
+// msm_g2.hip -- G2 instantiation of the MSM kernels: Fq2 over the radix-2^29 field (bn254_fq9.h, Fq2n)
 #include <algorithm>
 #include "msm_kernels.inc"
+
+int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out)
+{
+    if (n == 0) return K16_OK;
+    hipLaunchKernelGGL(k_convert_bases_g2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const k16::G2Aff*)d_bases, (k16::G2Aff*)d_out, n);
+    K16_HIP(ctx, hipGetLastError());
+    return K16_OK;
+}
 int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared)
 {
-    (void)prepared; // G2 rows are used as they are
-    return msm_enqueue_t<EngCanon<k16::Fq2>>(ctx, (const k16::G2Aff*)d_bases, d_scalars, n, c);
+    const k16::G2Aff* rows = (const k16::G2Aff*)d_bases;
+    if (!prepared) {
+        int rc = k16_ws_reserve(ctx, ctx->ws_conv, (size_t)n * sizeof(k16::G2Aff));
+        if (rc) return rc;
+        if ((rc = k16_msm_prepare_g2(ctx, d_bases, n, ctx->ws_conv.p))) return rc;
+        rows = (const k16::G2Aff*)ctx->ws_conv.p;
+    }
+    return msm_enqueue_t<Eng2n>(ctx, rows, d_scalars, n, c);
 }

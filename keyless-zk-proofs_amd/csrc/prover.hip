@@ -13,6 +13,7 @@
 // the decimal JSON stay on the host, using the same field code (bn254_field.h) compiled for x86.
 #include <fcntl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -380,6 +381,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // G1 tables -> the accumulate kernel's row layout, once (in place; see k16_msm_bases_prepare)
     if ((rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_A, nv, p->d_A)) ||
         (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_B1, nv, p->d_B1)) ||
+        (rc = k16_msm_bases_prepare(ctx, K16_G2, p->d_B2, nv, p->d_B2)) ||
         (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_C, nc, p->d_C)) ||
         (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_H, N, p->d_H))) {
         prover_free(p);
@@ -486,8 +488,23 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
 
     // groth16.cpp:88-112 : the four witness MSMs.  A, B1 and B2 share their scalars (the witness), so the
     // bucket sort of the A MSM is reused for B1 and B2.
+    // Witness scalars are mostly bits and bytes: all but the lowest windows are nearly empty, so the bucket
+    // reduction (W * 2^c adds) outweighs the accumulation at the reference's c = 16; c = 13 measured best
+    // (profiles/r01: 2.65 vs 3.05 ms at n = 2^20).  The H scalars are uniform and keep the automatic choice.
+    struct ForcedC {
+        k16_ctx* c;
+        unsigned saved;
+        ForcedC(k16_ctx* cx, unsigned v) : c(cx), saved(cx->forced_c) { if (!saved && cx_big(cx, v)) c->forced_c = v; }
+        static bool cx_big(k16_ctx*, unsigned) { return true; }
+        ~ForcedC() { c->forced_c = saved; }
+    };
     G1Xyzz pi_a, pib1, pi_c, pih;
     G2Xyzz pi_b;
+    unsigned wc = 13;
+    if (const char* e = getenv("K16_WITNESS_C")) wc = (unsigned)atoi(e);
+    if (p->n_vars < (1u << 17)) wc = 0; // small circuits: automatic
+    {
+    ForcedC fc(ctx, wc);
     if ((rc = msm_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars, &pi_a))) return rc;
     ctx->reuse_sort = true;
     if ((rc = msm_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars, &pib1))) return rc;
@@ -496,6 +513,7 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     if ((rc = msm_prepared(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1), (uint64_t)p->n_vars - p->n_public - 1,
                            &pi_c)))
         return rc;
+    }
     // groth16.cpp:281-283
     K16_HIP(ctx, hipStreamWaitEvent(st, p->ev_h, 0));
     if ((rc = msm_prepared(ctx, K16_G1, p->d_H, p->d_a, N, &pih))) return rc;

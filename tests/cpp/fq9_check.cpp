@@ -139,6 +139,83 @@ int main()
         Xyzz9  n3 = xyzz9_from_canonical(c3);
         CHECK(same_point_repr(padd_mixed9(n3, tab9[k]), padd_mixed(c3, tab[k])), "madd P+P (zz != 1)");
     }
+    // ---- Fq2 over Fq9 and the generic XYZZ formulas instantiated on it (G2)
+    {
+        auto rand_fq2 = [&]() { return Fq2{rand_fq(), rand_fq()}; };
+        auto ok2 = [&](const Fq2n& v) { return normalised(v.a) && normalised(v.b) && below_kp(v.a, 3) && below_kp(v.b, 3); };
+        for (int it = 0; it < 5000; it++) {
+            Fq2 a = rand_fq2(), b = rand_fq2();
+            if (it == 0) a = Fq2::zero();
+            if (it == 1) b = Fq2::one();
+            if (it == 2) { for (int i = 0; i < 8; i++) { a.a.v[i] = FqParams::P[i]; a.b.v[i] = FqParams::P[i]; } a.a.v[0] -= 1; a.b.v[0] -= 2; b = a; }
+            Fq2n A = fq2n_from_canonical(a), B = fq2n_from_canonical(b);
+            Fq2n m = fmul(A, B), sq = fsqr(A), ad = fadd(A, B), sb = fsub(A, B), ng = fneg(A), db = fdbl(A);
+            CHECK(ok2(m) && ok2(sq) && ok2(ad) && ok2(sb) && ok2(ng) && ok2(db), "fq2n invariant");
+            Fq2 cm = fq2n_to_canonical(m), wm = fmul(a, b);
+            CHECK(cm.a == wm.a && cm.b == wm.b, "fq2n mul");
+            Fq2 cs = fq2n_to_canonical(sq), ws = fsqr(a);
+            CHECK(cs.a == ws.a && cs.b == ws.b, "fq2n sqr");
+            Fq2 ca = fq2n_to_canonical(ad), wa = fadd(a, b);
+            CHECK(ca.a == wa.a && ca.b == wa.b, "fq2n add");
+            Fq2 cb = fq2n_to_canonical(sb), wb = fsub(a, b);
+            CHECK(cb.a == wb.a && cb.b == wb.b, "fq2n sub");
+            // chained: invariant must survive many operations
+            Fq2n x = A; Fq2 xc = a;
+            for (int k = 0; k < 20; k++) { x = fsub(fmul(fadd(x, B), x), fdbl(B)); xc = fsub(fmul(fadd(xc, b), xc), fdbl(b)); CHECK(ok2(x), "fq2n chain invariant"); }
+            Fq2 xx = fq2n_to_canonical(x);
+            CHECK(xx.a == xc.a && xx.b == xc.b, "fq2n chain value");
+            CHECK(fsub(A, A).is_zero() && !fadd(A, Fq2n::one()).is_zero() == !(fadd(a, Fq2::one()).is_zero()), "fq2n is_zero");
+        }
+        // G2 generator and a table
+        static const char* const G2S[4] = {
+            "10857046999023057135944570762232829481370756359578518086990519993285655852781",
+            "11559732032986387107991004021392285783925812861821192530917403151452391805634",
+            "8495653923123431417604973247489272438418190587263600148770280649306958101930",
+            "4082367875863433681332203403145435568316851327593401208105741076214120093531"};
+        Fq v[4];
+        Fq ten = Fq::zero(); ten.v[0] = 10; ten = to_mont(ten);
+        for (int k = 0; k < 4; k++) {
+            Fq acc = Fq::zero();
+            for (const char* p = G2S[k]; *p; p++) { Fq d = Fq::zero(); d.v[0] = (uint32_t)(*p - '0'); acc = fadd(fmul(acc, ten), to_mont(d)); }
+            v[k] = acc;
+        }
+        G2Aff g2{Fq2{v[0], v[1]}, Fq2{v[2], v[3]}};
+        const int N2 = 24;
+        G2Aff tb[N2]; Aff<Fq2n> tb9[N2];
+        G2Xyzz acc = G2Xyzz::zero();
+        for (int i = 0; i < N2; i++) {
+            acc = padd_mixed(acc, g2);
+            tb[i] = to_affine(acc);
+            if (i == 5) tb[i] = G2Aff{Fq2::zero(), Fq2::zero()};
+            tb9[i] = Aff<Fq2n>{fq2n_from_canonical(tb[i].x), fq2n_from_canonical(tb[i].y)};
+        }
+        auto same2 = [&](const Xyzz<Fq2n>& a, const G2Xyzz& b) {
+            if (b.is_zero()) return a.is_zero();
+            Fq2 x = fq2n_to_canonical(a.x), y = fq2n_to_canonical(a.y), zz = fq2n_to_canonical(a.zz), zzz = fq2n_to_canonical(a.zzz);
+            return x.a == b.x.a && x.b == b.x.b && y.a == b.y.a && y.b == b.y.b && zz.a == b.zz.a && zz.b == b.zz.b && zzz.a == b.zzz.a && zzz.b == b.zzz.b;
+        };
+        for (int walk = 0; walk < 60; walk++) {
+            G2Xyzz c = G2Xyzz::zero(), c2 = G2Xyzz::zero();
+            Xyzz<Fq2n> n = Xyzz<Fq2n>::zero(), n2 = Xyzz<Fq2n>::zero();
+            for (int step = 0; step < 40; step++) {
+                int op = (int)(rnd() % 7), k = (int)(rnd() % N2);
+                if (step == 1 || step == 2) { op = 0; k = 3; }
+                if (op <= 3) { c = padd_mixed(c, tb[k]); n = padd_mixed(n, tb9[k]); }
+                else if (op == 4) { c = pdbl(c); n = pdbl(n); }
+                else if (op == 5) { c2 = padd(c2, c); n2 = padd(n2, n); }
+                else { c = padd(c, c2); n = padd(n, n2); }
+                CHECK(ok2(n.x) && ok2(n.y) && ok2(n.zz) && ok2(n.zzz), "G2 point invariant");
+                CHECK(same2(n, c) && same2(n2, c2), "G2 XYZZ representation equal");
+            }
+            // P + (-P) through the mixed add
+            G2Xyzz cc = G2Xyzz::from_aff(tb[walk % N2 == 5 ? 6 : walk % N2]);
+            Xyzz<Fq2n> nn = Xyzz<Fq2n>::from_aff(tb9[walk % N2 == 5 ? 6 : walk % N2]);
+            G2Aff ng = pneg(tb[walk % N2 == 5 ? 6 : walk % N2]);
+            Aff<Fq2n> ng9{fq2n_from_canonical(ng.x), fq2n_from_canonical(ng.y)};
+            CHECK(padd_mixed(nn, ng9).is_zero() && padd_mixed(cc, ng).is_zero(), "G2 madd P+(-P)");
+            CHECK(same2(padd_mixed(nn, tb9[walk % N2 == 5 ? 6 : walk % N2]), padd_mixed(cc, tb[walk % N2 == 5 ? 6 : walk % N2])), "G2 madd P+P");
+        }
+    }
     printf(fails ? "FAILED %d checks\n" : "OK\n", fails);
     return fails ? 1 : 0;
 }
