@@ -95,7 +95,7 @@ def main():
     import k16
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("K16_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)

@@ -248,3 +248,28 @@ def test_synthetic_circuit_proof_bit_exact(ctx, tmp_path, shape):
     # witness handed over in memory gives the same proof
     assert p.prove_mem(w, r, s) == want
     p.close()
+
+
+def test_msm_g1_2p23_shard_closed_form(ctx):
+    """BASELINE config 5 shard size (2^26 points over 8 GPUs = 2^23 per GPU): bases (off+i+1)*G generated on the
+    device, scalars i+1, checked against the closed form sum (i+1)(off+i+1) * G; and the per-shard partials of two
+    such shards folded with k16_points_sum equal the closed form of the union (the multi-GPU combine)."""
+    import k16
+    n = 1 << 23
+    S = np.zeros((n, 32), dtype=np.uint8)
+    S[:, :4] = np.arange(1, n + 1, dtype=np.uint32).view(np.uint8).reshape(n, 4)
+    d_s = ctx.to_device(S)
+    parts = []
+    total = 0
+    for shard in range(2):
+        off = shard * n
+        d_b = ctx.synth_points(k16.G1, off, n)
+        x, _ = ctx.msm_device(k16.G1, d_b, d_s, n)
+        d_b.free()
+        want = sum_closed = (n * (n + 1) * (2 * n + 1) // 6 + off * n * (n + 1) // 2) % pm.R
+        assert ol.pt_eq(0, x, ol.mul_scalar(0, ol.generator(0), pm.limbs(want)))
+        parts.append(np.frombuffer(x, dtype=np.uint8))
+        total = (total + sum_closed) % pm.R
+    xs, _ = k16.points_sum(k16.G1, np.stack(parts))
+    assert ol.pt_eq(0, xs, ol.mul_scalar(0, ol.generator(0), pm.limbs(total)))
+    d_s.free()
