@@ -167,7 +167,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8 (256-bit Montgomery integers, 8 x 32-bit limbs)",
+            "dtype": "u64 column accumulators over 9 x 29-bit limbs (256-bit Montgomery integers, v_mad_u64_u32)",
             "data": "synthetic: bases (i+1)*G generated on device, scalars uniform in [0,r) (numpy seed 0xD1B5+rank)",
             "config": {
                 "workload": "BN254 G1 Pippenger MSM, 2^%d random scalars/points per GPU, result XYZZ on host"
@@ -177,7 +177,7 @@ def main():
                             else "single GPU",
             },
             "roofline": {
-                "kernel": "k_accumulate<Fq> (bucket accumulation, mixed adds)",
+                "kernel": "k_accumulate<Eng9> (bucket accumulation, XYZZ mixed adds)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

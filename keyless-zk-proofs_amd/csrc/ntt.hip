@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ a, const Fr* 
         const uint32_t mid = e >> TL, tl = e & (T - 1);
         st_fr(&tile[e], ld_fr(&a[base + ((size_t)mid << s0) + tl]));
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // see k16_lds_sync() in msm_kernels.inc
     __syncthreads();
     const uint32_t nbf = telem >> 1;
     for (uint32_t t = 1; t <= K; t++) {
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ a, const Fr* 
             tile[(m0 << TL) + tl] = fadd(tt, u);
             tile[(m1 << TL) + tl] = fsub(u, tt);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
     for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libk16.so")
+LIB_PATH = os.environ.get("K16_LIB_PATH") or os.path.join(HERE, "libk16.so")  # override: A/B-testing builds
 
 G1, G2 = 0, 1
 FQ, FR = 0, 1

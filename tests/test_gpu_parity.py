@@ -227,7 +227,7 @@ def test_toy_proof_bit_exact(ctx, toy_paths):
     p.close()
 
 
-@pytest.mark.parametrize("shape", [(3000, 2, 4096, 9000), (40000, 1, 1 << 16, 150000)])
+@pytest.mark.parametrize("shape", [(3000, 2, 4096, 9000), (40000, 1, 1 << 16, 150000), (140000, 1, 1 << 18, 400000)])
 def test_synthetic_circuit_proof_bit_exact(ctx, tmp_path, shape):
     """Non-toy prove(): random circuit of the given (nVars, nPublic, domainSize, nCoefs); the HIP proof JSON and
     the H scalars must equal the oracle's byte for byte (same witness, same injected r, s)."""
@@ -272,4 +272,38 @@ def test_msm_g1_2p23_shard_closed_form(ctx):
         total = (total + sum_closed) % pm.R
     xs, _ = k16.points_sum(k16.G1, np.stack(parts))
     assert ol.pt_eq(0, xs, ol.mul_scalar(0, ol.generator(0), pm.limbs(total)))
+    d_s.free()
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_msm_witness_like_large_forced_c13(ctx, group):
+    """The prover runs its witness MSMs with c = 13 once nVars >= 2^17; this exercises that configuration
+    (skewed scalars: one bucket holds ~45 % of the points -> sliced sort, giant-bucket fold) against the oracle."""
+    n = 150000
+    bases = ol.gen_points(group, 17, n)
+    bases[::3] = 0 if group == 1 else bases[::3]      # B2-like sparsity for G2
+    scalars = np_scalars(41 + group, n, "witness")
+    ctx.set_window_bits(13)
+    try:
+        _check_msm(ctx, group, bases, scalars, threads=8)
+    finally:
+        ctx.set_window_bits(0)
+
+
+def test_msm_repeatability_stress(ctx):
+    """Regression for a lost-update race (hipcc dropped the LDS wait of a barrier after a loop of no-return LDS
+    atomics; see k16_lds_sync in msm_kernels.inc): 300 launches on skewed input must all equal the oracle."""
+    n = 150000
+    bases = ol.gen_points(0, 17, n)
+    scalars = np_scalars(41, n, "witness")
+    _, want = ol.msm(0, bases, scalars, nthreads=8)
+    d_b, d_s = ctx.to_device(bases), ctx.to_device(scalars)
+    for c in (13, 0):
+        ctx.set_window_bits(c)
+        try:
+            bad = [i for i in range(150) if ctx.msm_device(0, d_b, d_s, n)[1] != want]
+        finally:
+            ctx.set_window_bits(0)
+        assert bad == []
+    d_b.free()
     d_s.free()
