@@ -16,7 +16,7 @@ int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_ou
 namespace {
 constexpr unsigned MAX_C = 16;
 constexpr unsigned MIN_C = 4;
-inline unsigned n_windows(unsigned c) { return (256 + c - 1) / c; }
+inline unsigned n_windows(unsigned c) { return (256 + c - 1) / c + 1; } // + carry window of the signed recoding
 
 unsigned choose_c(const k16_ctx* ctx, uint64_t n)
 {
@@ -29,14 +29,14 @@ unsigned choose_c(const k16_ctx* ctx, uint64_t n)
     return (unsigned)c;
 }
 
-// Host tail of the MSM: per window  val = T[nbits] + M * sum_b 2^b T[b]  (see msm_kernels.inc, K4),
+// Host tail of the MSM: per window  val = T[nbits] + T[nbits+1] + M * sum_b 2^b T[b]  (msm_kernels.inc, K4),
 // then the Horner combine over windows (multiexp.cpp:236-242).
 template <class F>
 void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
 {
     Xyzz<F> r = Xyzz<F>::zero();
     for (int w = (int)W - 1; w >= 0; w--) {
-        const Xyzz<F>* tw = T + (size_t)w * (nbits + 1);
+        const Xyzz<F>* tw = T + (size_t)w * (nbits + 2);
         Xyzz<F>        t  = Xyzz<F>::zero();
         for (int b = (int)nbits - 1; b >= 0; b--) {
             t = pdbl(t);
@@ -44,6 +44,7 @@ void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsig
         }
         for (unsigned k = 0; k < mlog; k++) t = pdbl(t);
         t = padd(t, tw[nbits]);
+        t = padd(t, tw[nbits + 1]); // + sum of all X: slot i' carries the weight i' + 1
         for (unsigned k = 0; k < c; k++) r = pdbl(r);
         r = padd(r, t);
     }
@@ -114,7 +115,7 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
     if (group == K16_G1) {
         // the G1 kernels work in the radix-2^29 / R' domain: bring the few window/bit sums back to the
         // reference's canonical Montgomery form first (exact conversion)
-        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 1);
+        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 2);
         std::vector<G1Xyzz> T(cnt);
         for (unsigned i = 0; i < cnt; i++) {
             Xyzz9 p9;
@@ -129,7 +130,7 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
             memcpy(h_out_affine, &a, sizeof a);
         }
     } else {
-        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 1);
+        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 2);
         std::vector<G2Xyzz> T(cnt);
         for (unsigned i = 0; i < cnt; i++) {
             Xyzz<Fq2n> p9;
