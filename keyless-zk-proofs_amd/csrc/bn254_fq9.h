@@ -23,29 +23,49 @@ struct Fq9 {
     uint32_t l[9];
 };
 
-namespace fq9c {
-constexpr uint32_t MASK = (1u << 29) - 1;
+struct Fq9C {
+static constexpr uint32_t MASK = (1u << 29) - 1;
 // p in radix 2^29
-constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+static constexpr uint32_t P[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
                            0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
-constexpr uint32_t NP   = 0x04866389u; // -p^-1 mod 2^29
+static constexpr uint32_t NP   = 0x04866389u; // -p^-1 mod 2^29
 // R' mod p  (Montgomery one)
-constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+static constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
                              0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
 // 2^266 mod p = R'^2 / R : fmul9(x*R, K_IN) = x*R'
-constexpr uint32_t K_IN[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u,
+static constexpr uint32_t K_IN[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u,
                               0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
 // 2^256 mod p = R : fmul9(x*R', K_OUT) = x*R
-constexpr uint32_t K_OUT[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
+static constexpr uint32_t K_OUT[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
                                0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
 // k*p for the subtraction offsets
-constexpr uint32_t KP2[9] = {0x10f9fa8eu, 0x0208c16du, 0x18e5469eu, 0x05aa45a1u, 0x0b0bb2f0u,
+static constexpr uint32_t KP2[9] = {0x10f9fa8eu, 0x0208c16du, 0x18e5469eu, 0x05aa45a1u, 0x0b0bb2f0u,
                              0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
-constexpr uint32_t KP4[9] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u,
+static constexpr uint32_t KP4[9] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u,
                              0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
-constexpr uint32_t KP8[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u,
+static constexpr uint32_t KP8[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u,
                              0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
-} // namespace fq9c
+};
+// the same for the scalar field r (NTT chain): r in radix 2^29, -r^-1 mod 2^29, 2^261 / 2^266 / 2^256 mod r, k*r
+struct Fr9C {
+    static constexpr uint32_t MASK = (1u << 29) - 1;
+    static constexpr uint32_t P[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t NP   = 0x0fffffffu;
+    static constexpr uint32_t ONE[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                        0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+    static constexpr uint32_t K_IN[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau,
+                                         0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+    static constexpr uint32_t K_OUT[9] = {0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu,
+                                          0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+    static constexpr uint32_t KP2[9] = {0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u,
+                                        0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+    static constexpr uint32_t KP4[9] = {0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu,
+                                        0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+    static constexpr uint32_t KP8[9] = {0x00000008u, 0x187d64fcu, 0x12e12287u, 0x1e84879bu, 0x0c2e9419u,
+                                        0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
+};
+
 
 K16_HD Fq9 fq9_zero()
 {
@@ -58,7 +78,7 @@ K16_HD Fq9 fq9_one()
 {
     Fq9 r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = fq9c::ONE[i];
+    for (int i = 0; i < 9; i++) r.l[i] = Fq9C::ONE[i];
     return r;
 }
 K16_HD bool fq9_limbs_zero(const Fq9& a)
@@ -72,7 +92,8 @@ K16_HD bool fq9_limbs_zero(const Fq9& a)
 // Montgomery product for radix 2^29: returns a*b/R' mod p, < p*(1 + A*B/169); limbs normalised.
 // Needs normalised inputs (l[0..7] < 2^29, l[8] < 2^29).  Product scanning; column k collects the
 // a_i*b_j with i+j = k and the m_i*p_j reduction terms; m_k clears the low 29 bits of column k.
-K16_HD Fq9 fmul9(const Fq9& a, const Fq9& b)
+template <class C>
+K16_HD Fq9 fmul9_t(const Fq9& a, const Fq9& b)
 {
     uint32_t m[9];
     Fq9      r;
@@ -86,22 +107,23 @@ K16_HD Fq9 fmul9(const Fq9& a, const Fq9& b)
             if (j < 0 || j > 8) continue;
             acc += (uint64_t)a.l[i] * b.l[j];
             if (i < k || k >= 9) {
-                if (i <= 8 && (k >= 9 || i < k)) acc2 += (uint64_t)m[i] * fq9c::P[j];
+                if (i <= 8 && (k >= 9 || i < k)) acc2 += (uint64_t)m[i] * C::P[j];
             }
         }
         acc += acc2;
         if (k < 9) {
-            m[k] = ((uint32_t)acc * fq9c::NP) & fq9c::MASK;
-            acc += (uint64_t)m[k] * fq9c::P[0];
+            m[k] = ((uint32_t)acc * C::NP) & C::MASK;
+            acc += (uint64_t)m[k] * C::P[0];
             acc >>= 29;
         } else {
-            r.l[k - 9] = (uint32_t)acc & fq9c::MASK;
+            r.l[k - 9] = (uint32_t)acc & C::MASK;
             acc >>= 29;
         }
     }
     r.l[8] = (uint32_t)acc;
     return r;
 }
+K16_HD Fq9 fmul9(const Fq9& a, const Fq9& b) { return fmul9_t<Fq9C>(a, b); }
 K16_HD Fq9 fsqr9(const Fq9& a) { return fmul9(a, a); }
 
 // a + b (bound A + B); limbs renormalised
@@ -112,7 +134,7 @@ K16_HD Fq9 fadd9(const Fq9& a, const Fq9& b)
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         uint32_t t = a.l[i] + b.l[i] + c;
-        r.l[i]     = t & fq9c::MASK;
+        r.l[i]     = t & Fq9C::MASK;
         c          = t >> 29;
     }
     r.l[8] = a.l[8] + b.l[8] + c;
@@ -122,23 +144,29 @@ K16_HD Fq9 fdbl9(const Fq9& a) { return fadd9(a, a); }
 
 // a - b + K*p, K in {2, 4, 8}; needs b < K*p; result < A + K.  Signed limb-wise difference with an
 // arithmetic-shift carry; the total is non-negative so the top limb ends >= 0.
-template <int K>
-K16_HD Fq9 fsub9(const Fq9& a, const Fq9& b)
+template <class C, int K>
+K16_HD Fq9 fsub9_t(const Fq9& a, const Fq9& b)
 {
     Fq9     r;
     int32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        const uint32_t kp = K == 2 ? fq9c::KP2[i] : (K == 4 ? fq9c::KP4[i] : fq9c::KP8[i]);
+        const uint32_t kp = K == 2 ? C::KP2[i] : (K == 4 ? C::KP4[i] : C::KP8[i]);
         int32_t        t  = (int32_t)(a.l[i] + kp) - (int32_t)b.l[i] + c;
         if (i < 8) {
-            r.l[i] = (uint32_t)t & fq9c::MASK;
+            r.l[i] = (uint32_t)t & C::MASK;
             c      = t >> 29;
         } else {
             r.l[8] = (uint32_t)t;
         }
     }
     return r;
+}
+
+template <int K>
+K16_HD Fq9 fsub9(const Fq9& a, const Fq9& b)
+{
+    return fsub9_t<Fq9C, K>(a, b);
 }
 
 // exact comparison with j*p, j = 0 .. J-1, for a normalised value < J*p:  V == 0 (mod p) ?
@@ -160,17 +188,17 @@ K16_HD bool fq9_is_zero_mod_p(const Fq9& a)
         // v >= p ?
         bool ge = true;
         for (int i = 8; i >= 0; i--) {
-            if (v.l[i] != fq9c::P[i]) {
-                ge = v.l[i] > fq9c::P[i];
+            if (v.l[i] != Fq9C::P[i]) {
+                ge = v.l[i] > Fq9C::P[i];
                 break;
             }
         }
         if (!ge) break;
         int32_t c = 0;
         for (int i = 0; i < 9; i++) {
-            int32_t t = (int32_t)v.l[i] - (int32_t)fq9c::P[i] + c;
+            int32_t t = (int32_t)v.l[i] - (int32_t)Fq9C::P[i] + c;
             if (i < 8) {
-                v.l[i] = (uint32_t)t & fq9c::MASK;
+                v.l[i] = (uint32_t)t & Fq9C::MASK;
                 c      = t >> 29;
             } else {
                 v.l[8] = (uint32_t)t;
@@ -189,7 +217,7 @@ K16_HD Fq9 fq9_unpack(const uint32_t w[8])
         const int bit = 29 * i, wd = bit >> 5, sh = bit & 31;
         uint64_t  v = w[wd];
         if (wd + 1 < 8) v |= (uint64_t)w[wd + 1] << 32;
-        r.l[i] = (uint32_t)(v >> sh) & (i < 8 ? fq9c::MASK : 0xffffffffu);
+        r.l[i] = (uint32_t)(v >> sh) & (i < 8 ? Fq9C::MASK : 0xffffffffu);
     }
     return r;
 }
@@ -213,7 +241,7 @@ K16_HD Fq9 fq9_from_fq(const Fq& x)
 {
     Fq9 k;
 #pragma unroll
-    for (int i = 0; i < 9; i++) k.l[i] = fq9c::K_IN[i];
+    for (int i = 0; i < 9; i++) k.l[i] = Fq9C::K_IN[i];
     return fmul9(fq9_unpack(x.v), k);
 }
 // Fq9 (any bound <= 12p)  ->  canonical Montgomery Fq (< p)
@@ -221,7 +249,7 @@ K16_HD Fq fq9_to_fq(const Fq9& a)
 {
     Fq9 k;
 #pragma unroll
-    for (int i = 0; i < 9; i++) k.l[i] = fq9c::K_OUT[i];
+    for (int i = 0; i < 9; i++) k.l[i] = Fq9C::K_OUT[i];
     Fq9 v = fmul9(a, k); // = x*R, < 2p
     Fq  r;
     fq9_pack(r.v, v);
@@ -339,7 +367,8 @@ K16_HD Xyzz9 xyzz9_from_canonical(const Xyzz<Fq>& p)
 // With the invariant in place the generic XYZZ formulas of bn254_curve.h apply unchanged (G2).
 // ------------------------------------------------------------------------------------------------
 // v < 16p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17))
-K16_HD Fq9 fred9(const Fq9& v)
+template <class C>
+K16_HD Fq9 fred9_t(const Fq9& v)
 {
     const uint32_t t = v.l[8];
     uint32_t       q = (uint32_t)(((uint64_t)t * 5547123ull) >> 44); // floor(t / 3171407) or one less
@@ -348,9 +377,9 @@ K16_HD Fq9 fred9(const Fq9& v)
     int64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        int64_t x = (int64_t)v.l[i] - (int64_t)((uint64_t)q * fq9c::P[i]) + c;
+        int64_t x = (int64_t)v.l[i] - (int64_t)((uint64_t)q * C::P[i]) + c;
         if (i < 8) {
-            r.l[i] = (uint32_t)x & fq9c::MASK;
+            r.l[i] = (uint32_t)x & C::MASK;
             c      = x >> 29;
         } else {
             r.l[8] = (uint32_t)x;
@@ -358,6 +387,8 @@ K16_HD Fq9 fred9(const Fq9& v)
     }
     return r;
 }
+
+K16_HD Fq9 fred9(const Fq9& v) { return fred9_t<Fq9C>(v); }
 
 struct Fq2n {
     Fq9 a, b;
@@ -387,5 +418,48 @@ K16_HD Fq2n fsqr(const Fq2n& x)
 
 K16_HD Fq2n fq2n_from_canonical(const Fq2& x) { return Fq2n{fq9_from_fq(x.a), fq9_from_fq(x.b)}; }
 K16_HD Fq2  fq2n_to_canonical(const Fq2n& x) { return Fq2{fq9_to_fq(x.a), fq9_to_fq(x.b)}; }
+
+
+// ------------------------------------------------------------------------------------------------
+// Fr on the same representation (the NTT / polynomial chain).  An Fr9 is a 9-limb value congruent to
+// x * 2^261 mod r, kept < 2r (+ 2^-17 r) between operations by frred9; "packed" = the same value as
+// 8 x 32-bit words (what the kernels keep in HBM for a, b, c and the twiddle table).
+// ------------------------------------------------------------------------------------------------
+typedef Fq9 Fr9;
+K16_HD Fr9 frmul9(const Fr9& a, const Fr9& b) { return fmul9_t<Fr9C>(a, b); }
+K16_HD Fr9 fradd9(const Fr9& a, const Fr9& b) { return fred9_t<Fr9C>(fadd9(a, b)); }      // < 4r -> < 2r
+K16_HD Fr9 frsub9(const Fr9& a, const Fr9& b) { return fred9_t<Fr9C>(fsub9_t<Fr9C, 2>(a, b)); } // b < 2r
+K16_HD Fr9 fr9_load(const uint32_t w[8]) { return fq9_unpack(w); }
+K16_HD void fr9_store(uint32_t w[8], const Fr9& a) { fq9_pack(w, a); }                    // a < 2^256
+// canonical Montgomery Fr (R = 2^256) -> Fr9, and back (exact, canonical result)
+K16_HD Fr9 fr9_from_fr(const Fr& x)
+{
+    Fr9 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = Fr9C::K_IN[i];
+    return fmul9_t<Fr9C>(fq9_unpack(x.v), k);
+}
+K16_HD Fr fr9_to_fr(const Fr9& a)
+{
+    Fr9 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = Fr9C::K_OUT[i];
+    Fr9 v = fmul9_t<Fr9C>(a, k);
+    Fr  r;
+    fq9_pack(r.v, v);
+    cond_sub_p<FrParams>(r.v);
+    return r;
+}
+// Fr9 (x * 2^261) -> the STANDARD-form integer x, canonical (what the H MSM consumes: groth16.cpp:273)
+K16_HD Fr fr9_to_standard(const Fr9& a)
+{
+    Fr9 one = fq9_zero();
+    one.l[0] = 1;
+    Fr9 v = fmul9_t<Fr9C>(a, one); // x * 2^261 / 2^261 = x, < 2r
+    Fr  r;
+    fq9_pack(r.v, v);
+    cond_sub_p<FrParams>(r.v);
+    return r;
+}
 
 } // namespace k16

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include "../../include/k16.h"
 #include "bn254_curve.h"
+#include "bn254_fq9.h"
 
 struct k16_devbuf {
     void*  p     = nullptr;
@@ -20,8 +21,10 @@ struct k16_kstat {
 
 struct k16_ntt_table {
     uint32_t  s      = 0; // log2 size
-    k16::Fr*  roots  = nullptr; // device, 2^s entries, Montgomery
+    k16::Fr*  roots  = nullptr; // device, 2^s entries, canonical Montgomery (R = 2^256)
+    k16::Fr*  roots9 = nullptr; // device, the same roots as packed R' values (x * 2^261 mod r), see bn254_fq9.h
     k16::Fr   pow2inv[34];
+    k16::Fq9  pow2inv9[34];     // 2^-k as Fr9
 };
 
 struct k16_ctx {
@@ -90,4 +93,4 @@ struct k16_stat_scope {
 
 // host-side helpers implemented in msm.hip
 int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out);
-int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st);
+int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st, int packed9);

@@ -55,6 +55,8 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
         if (b->p) (void)hipFree(b->p);
     for (auto& kv : c->ntt_tables)
         if (kv.second.roots) (void)hipFree(kv.second.roots);
+    for (auto& kv : c->ntt_tables)
+        if (kv.second.roots9) (void)hipFree(kv.second.roots9);
     if (c->pinned) (void)hipHostFree(c->pinned);
     (void)hipEventDestroy(c->ev_a);
     (void)hipEventDestroy(c->ev_b);

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 #include "ctx.h"
+#include "bn254_fq9.h"
 
 using namespace k16;
 
@@ -106,40 +107,56 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& r)
     d[1]     = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
 
+// The polynomial chain works on the radix-2^29 representation of Fr (bn254_fq9.h): a, b, c live in HBM as
+// packed R' values (x * 2^261 mod r, < 2r, 32 bytes), the coefficients are stored pre-multiplied by 2^522
+// (the reference's zkey stores them pre-multiplied by R^2 = 2^512 for the same reason), and only the
+// final H scalars are brought back to the canonical standard form the MSM consumes.  Field values are exact
+// mod r throughout, so the H scalars are bit-identical to the reference's (tests compare them).
+__device__ __forceinline__ Fr9 ld_r9(const Fr* p)
+{
+    Fr w = ld_fr(p);
+    return fr9_load(w.v);
+}
+__device__ __forceinline__ void st_r9(Fr* p, const Fr9& v)
+{
+    Fr w;
+    fr9_store(w.v, v);
+    st_fr(p, w);
+}
 // groth16.cpp:137-156 : ab[c] += wtns[s] (x) coef.  The zkey's coefficient list is regrouped once at
 // load time into CSR rows (matrix m, constraint c), so each lane owns one output element and no
 // 256-bit atomics / spinlocks are needed.  Field addition is exact, so the summation order is free.
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ wire,
-                                              const Fr* __restrict__ coef, const Fr* __restrict__ wtns,
+                                              const Fr* __restrict__ coef9, const Fr* __restrict__ wtns,
                                               Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * N) return;
     uint32_t lo = row_ptr[t], hi = row_ptr[t + 1];
-    Fr       acc = Fr::zero();
-    for (uint32_t k = lo; k < hi; k++) acc = fadd(acc, fmul(ld_fr(&wtns[wire[k]]), ld_fr(&coef[k])));
-    st_fr(t < N ? &a[t] : &b[t - N], acc);
+    Fr9      acc = fq9_zero();
+    for (uint32_t k = lo; k < hi; k++) acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[k]]), ld_r9(&coef9[k])));
+    st_r9(t < N ? &a[t] : &b[t - N], acc);
 }
 // groth16.cpp:160-167
 __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __restrict__ a, const Fr* __restrict__ b,
                                              uint32_t N)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) st_fr(&c[i], fmul(ld_fr(&a[i]), ld_fr(&b[i])));
+    if (i < N) st_r9(&c[i], frmul9(ld_r9(&a[i]), ld_r9(&b[i])));
 }
 // groth16.cpp:182-190 : x[i] *= root(log2N + 1, i) = roots[i << (S - log2N - 1)]
-__global__ void __launch_bounds__(256) k_shift(Fr* __restrict__ x, const Fr* __restrict__ roots, uint32_t N,
+__global__ void __launch_bounds__(256) k_shift(Fr* __restrict__ x, const Fr* __restrict__ roots9, uint32_t N,
                                                uint32_t stride_log)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) st_fr(&x[i], fmul(ld_fr(&x[i]), ld_fr(&roots[(size_t)i << stride_log])));
+    if (i < N) st_r9(&x[i], frmul9(ld_r9(&x[i]), ld_r9(&roots9[(size_t)i << stride_log])));
 }
-// groth16.cpp:266-275 : a = fromMontgomery(a*b - c)
+// groth16.cpp:266-275 : a = fromMontgomery(a*b - c)  (standard form, canonical: the H MSM's scalars)
 __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ a, const Fr* __restrict__ b,
                                                   const Fr* __restrict__ c, uint32_t N)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) st_fr(&a[i], from_mont(fsub(fmul(ld_fr(&a[i]), ld_fr(&b[i])), ld_fr(&c[i]))));
+    if (i < N) st_fr(&a[i], fr9_to_standard(frsub9(frmul9(ld_r9(&a[i]), ld_r9(&b[i])), ld_r9(&c[i]))));
 }
 
 // ---------------------------------------------------------------- host helpers
@@ -352,7 +369,11 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         memcpy(&s, cf + i * 44 + 8, 4);
         uint32_t pos = fill[(m == 0 ? 0 : N) + c]++;
         wire[pos]    = s;
-        memcpy(&vals[(size_t)pos * 32], cf + i * 44 + 12, 32);
+        // stored value = coef * 2^512 mod r (canonical); the Fr9 kernels want coef * 2^522: ten modular doublings
+        Fr cv;
+        memcpy(cv.v, cf + i * 44 + 12, 32);
+        for (int d = 0; d < 10; d++) cv = fdbl(cv);
+        memcpy(&vals[(size_t)pos * 32], cv.v, 32);
     }
 
     K16_HIP_P(ctx, hipSetDevice(ctx->device), p);
@@ -478,9 +499,9 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N);
     Fr* vec[3] = {p->d_a, p->d_b, p->d_c};
     for (int k = 0; k < 3; k++) {
-        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 1, s2))) return rc;
-        hipLaunchKernelGGL(k_shift, dim3(gN), dim3(256), 0, s2, vec[k], p->ntt->roots, N, p->ntt->s - p->logN - 1);
-        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 0, s2))) return rc;
+        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 1, s2, 1))) return rc;
+        hipLaunchKernelGGL(k_shift, dim3(gN), dim3(256), 0, s2, vec[k], p->ntt->roots9, N, p->ntt->s - p->logN - 1);
+        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 0, s2, 1))) return rc;
     }
     hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_b, p->d_c, N);
     K16_HIP(ctx, hipGetLastError());

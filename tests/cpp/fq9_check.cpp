@@ -34,8 +34,8 @@ static bool below_kp(const Fq9& v, int K)
 {
     uint64_t kp[9], c = 0;
     for (int i = 0; i < 9; i++) {
-        uint64_t t = (uint64_t)fq9c::P[i] * K + c;
-        if (i < 8) { kp[i] = t & fq9c::MASK; c = t >> 29; } else kp[i] = t;
+        uint64_t t = (uint64_t)Fq9C::P[i] * K + c;
+        if (i < 8) { kp[i] = t & Fq9C::MASK; c = t >> 29; } else kp[i] = t;
     }
     for (int i = 8; i >= 0; i--) {
         if (v.l[i] != kp[i]) return v.l[i] < kp[i];
@@ -138,6 +138,38 @@ int main()
         G1Xyzz c3 = padd_mixed(padd_mixed(c, tab[(k + 1) % NP == 7 ? 8 : (k + 1) % NP]), pneg(tab[(k + 1) % NP == 7 ? 8 : (k + 1) % NP]));
         Xyzz9  n3 = xyzz9_from_canonical(c3);
         CHECK(same_point_repr(padd_mixed9(n3, tab9[k]), padd_mixed(c3, tab[k])), "madd P+P (zz != 1)");
+    }
+    // ---- Fr on the same representation (NTT chain): values, the < 2r invariant, conversions
+    {
+        auto rand_fr = [&]() { Fr x; for (int i = 0; i < 8; i += 2) { uint64_t r = rnd(); x.v[i] = (uint32_t)r; x.v[i + 1] = (uint32_t)(r >> 32); } x.v[7] &= 0x0fffffff; return x; };
+        auto below_kr = [&](const Fr9& v, int K) {
+            uint64_t kp[9], c = 0;
+            for (int i = 0; i < 9; i++) { uint64_t t = (uint64_t)Fr9C::P[i] * K + c; if (i < 8) { kp[i] = t & Fr9C::MASK; c = t >> 29; } else kp[i] = t; }
+            for (int i = 8; i >= 0; i--) if (v.l[i] != kp[i]) return v.l[i] < kp[i];
+            return false;
+        };
+        for (int it = 0; it < 20000; it++) {
+            Fr a = rand_fr(), b = rand_fr();
+            if (it == 0) a = Fr::zero();
+            if (it == 1) a = Fr::one();
+            if (it == 2) { for (int i = 0; i < 8; i++) a.v[i] = FrParams::P[i]; a.v[0] -= 1; b = a; }
+            Fr9 A = fr9_from_fr(a), B = fr9_from_fr(b);
+            CHECK(fr9_to_fr(A) == a, "fr roundtrip");
+            CHECK(fr9_to_fr(frmul9(A, B)) == fmul(a, b), "fr mul");
+            Fr9 s = fradd9(A, B), d = frsub9(A, B);
+            CHECK(normalised(s) && below_kr(s, 3) && normalised(d) && below_kr(d, 3), "fr invariant");
+            CHECK(fr9_to_fr(s) == fadd(a, b) && fr9_to_fr(d) == fsub(a, b), "fr add/sub");
+            CHECK(fr9_to_standard(A) == from_mont(a), "fr to standard form");
+            // packed round trip (what the kernels keep in HBM)
+            uint32_t w[8]; fr9_store(w, s); Fr9 s2 = fr9_load(w);
+            bool same = true; for (int i = 0; i < 9; i++) same &= s2.l[i] == s.l[i];
+            CHECK(same, "fr pack/unpack");
+            // a butterfly chain keeps the invariant
+            Fr9 u = A, tt = B; Fr uc = a, tc = b;
+            for (int k = 0; k < 24; k++) { Fr9 m = frmul9(tt, B); Fr mc = fmul(tc, b); Fr9 nu = fradd9(u, m); tt = frsub9(u, m); u = nu; Fr nuc = fadd(uc, mc); tc = fsub(uc, mc); uc = nuc;
+                CHECK(below_kr(u, 3) && below_kr(tt, 3), "fr butterfly invariant"); }
+            CHECK(fr9_to_fr(u) == uc && fr9_to_fr(tt) == tc, "fr butterfly chain");
+        }
     }
     // ---- Fq2 over Fq9 and the generic XYZZ formulas instantiated on it (G2)
     {
