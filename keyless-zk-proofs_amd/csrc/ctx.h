@@ -47,9 +47,22 @@ struct k16_ctx {
     size_t pinned_bytes = 0;
 
     // state of the MSM currently enqueued (k16_msm_enqueue -> k16_msm_finish)
-    int      pend_group = -1;
-    unsigned pend_c = 0, pend_w = 0, pend_nbits = 0;
-    uint64_t pend_n = 0;
+    // MSMs enqueued and not yet finished (FIFO): several can be in flight on the stream, each with its own
+    // slot of the pinned staging buffer and an event recorded after its device-to-host copy, so the host
+    // tail of one MSM (conversion + Horner) overlaps the next MSM's kernels
+    static constexpr int    PEND_SLOTS = 8;
+    static constexpr size_t SLOT_BYTES = 80 * 1024;
+    struct Pend {
+        int      group = -1;
+        unsigned c = 0, w = 0, nbits = 0;
+        uint64_t n = 0;
+        int      slot = 0;
+    };
+    Pend       pend[PEND_SLOTS];
+    int        pend_head = 0, pend_count = 0; // ring: oldest at pend_head
+    hipEvent_t pend_ev[PEND_SLOTS] = {};
+    int        enq_slot = 0;                  // staging slot of the MSM being enqueued
+    unsigned   pend_nbits = 0;                // written by the kernels' host code for the MSM being enqueued
 
     // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2
     // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)

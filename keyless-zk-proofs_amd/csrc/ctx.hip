@@ -34,11 +34,16 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
         delete c;
         return K16_ERR_NO_DEVICE;
     }
-    c->pinned_bytes = 1 << 17;
+    c->pinned_bytes = k16_ctx::PEND_SLOTS * k16_ctx::SLOT_BYTES + 65536; // + debug area
     if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return K16_ERR_NO_DEVICE;
     }
+    for (int i = 0; i < k16_ctx::PEND_SLOTS; i++)
+        if (hipEventCreateWithFlags(&c->pend_ev[i], hipEventDisableTiming) != hipSuccess) {
+            delete c;
+            return K16_ERR_NO_DEVICE;
+        }
     *out = c;
     return K16_OK;
 }
@@ -58,6 +63,8 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     for (auto& kv : c->ntt_tables)
         if (kv.second.roots9) (void)hipFree(kv.second.roots9);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (int i = 0; i < k16_ctx::PEND_SLOTS; i++)
+        if (c->pend_ev[i]) (void)hipEventDestroy(c->pend_ev[i]);
     (void)hipEventDestroy(c->ev_a);
     (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ks_pool) (void)hipEventDestroy(e);

@@ -64,18 +64,34 @@ extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
 static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, int prepared)
 {
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
-    if (n >= (1ull << 32) / 64) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
+    if (n >= (1ull << 32) / 80) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
         ctx->err = "k16_msm: n too large for one device call; shard it";
         return K16_ERR_ARG;
     }
-    ctx->pend_group = group;
-    ctx->pend_n     = n;
-    if (n == 0) return K16_OK;
-    unsigned c  = choose_c(ctx, n);
-    ctx->pend_c = c;
-    ctx->pend_w = n_windows(c);
-    if (group == K16_G1) return k16_msm_enqueue_g1(ctx, d_bases, d_scalars, n, c, prepared);
-    return k16_msm_enqueue_g2(ctx, d_bases, d_scalars, n, c, prepared);
+    if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
+        ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
+        return K16_ERR_ARG;
+    }
+    const int     idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
+    k16_ctx::Pend pd;
+    pd.group = group;
+    pd.n     = n;
+    pd.slot  = idx;
+    int rc   = K16_OK;
+    if (n != 0) {
+        unsigned c    = choose_c(ctx, n);
+        pd.c          = c;
+        pd.w          = n_windows(c);
+        ctx->enq_slot = idx;
+        rc = group == K16_G1 ? k16_msm_enqueue_g1(ctx, d_bases, d_scalars, n, c, prepared)
+                             : k16_msm_enqueue_g2(ctx, d_bases, d_scalars, n, c, prepared);
+        if (rc) return rc;
+        pd.nbits = ctx->pend_nbits;
+        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->stream));
+    }
+    ctx->pend[idx] = pd;
+    ctx->pend_count++;
+    return K16_OK;
 }
 
 extern "C" int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n)
@@ -96,10 +112,12 @@ extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_base
 
 extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
 {
-    if (!ctx || ctx->pend_group < 0) return K16_ERR_ARG;
-    int group       = ctx->pend_group;
-    ctx->pend_group = -1;
-    if (ctx->pend_n == 0) {
+    if (!ctx || ctx->pend_count == 0) return K16_ERR_ARG;
+    const k16_ctx::Pend pd = ctx->pend[ctx->pend_head];
+    ctx->pend_head         = (ctx->pend_head + 1) % k16_ctx::PEND_SLOTS;
+    ctx->pend_count--;
+    const int group = pd.group;
+    if (pd.n == 0) {
         if (group == K16_G1) {
             G1Xyzz z = G1Xyzz::zero();
             if (h_out_xyzz) memcpy(h_out_xyzz, &z, sizeof z);
@@ -111,36 +129,36 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
         }
         return K16_OK;
     }
-    K16_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    K16_HIP(ctx, hipEventSynchronize(ctx->pend_ev[pd.slot])); // only this MSM's results; later ones keep running
+    const char*    src = (const char*)ctx->pinned + (size_t)pd.slot * k16_ctx::SLOT_BYTES;
+    const unsigned cnt = pd.w * (pd.nbits + 2);
     if (group == K16_G1) {
         // the G1 kernels work in the radix-2^29 / R' domain: bring the few window/bit sums back to the
         // reference's canonical Montgomery form first (exact conversion)
-        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 2);
         std::vector<G1Xyzz> T(cnt);
         for (unsigned i = 0; i < cnt; i++) {
             Xyzz9 p9;
-            memcpy(&p9, (const char*)ctx->pinned + (size_t)i * sizeof(Xyzz9), sizeof p9);
+            memcpy(&p9, src + (size_t)i * sizeof(Xyzz9), sizeof p9);
             T[i] = xyzz9_to_canonical(p9);
         }
         G1Xyzz r;
-        horner_host<Fq>(T.data(), ctx->pend_w, ctx->pend_c, ctx->pend_nbits, 3, &r);
+        horner_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, 3, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G1Aff a = to_affine(r);
             memcpy(h_out_affine, &a, sizeof a);
         }
     } else {
-        const unsigned     cnt = ctx->pend_w * (ctx->pend_nbits + 2);
         std::vector<G2Xyzz> T(cnt);
         for (unsigned i = 0; i < cnt; i++) {
             Xyzz<Fq2n> p9;
-            memcpy(&p9, (const char*)ctx->pinned + (size_t)i * sizeof p9, sizeof p9);
+            memcpy(&p9, src + (size_t)i * sizeof p9, sizeof p9);
             T[i] = p9.is_zero() ? G2Xyzz::zero()
                                 : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
                                          fq2n_to_canonical(p9.zzz)};
         }
         G2Xyzz r;
-        horner_host<Fq2>(T.data(), ctx->pend_w, ctx->pend_c, ctx->pend_nbits, 3, &r);
+        horner_host<Fq2>(T.data(), pd.w, pd.c, pd.nbits, 3, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G2Aff a = to_affine(r);

@@ -307,3 +307,31 @@ def test_msm_repeatability_stress(ctx):
         assert bad == []
     d_b.free()
     d_s.free()
+
+
+def test_generic_atomic_sort_path_agrees(ctx, monkeypatch):
+    """n > 2^24 uses the generic global-atomic bucket sort instead of the LDS partition sort; force it on a small
+    input and compare with the oracle (K16_ATOMIC_SORT is read at every call)."""
+    n = 5000
+    bases = ol.gen_points(0, 3, n)
+    monkeypatch.setenv("K16_ATOMIC_SORT", "1")
+    for kind in ("full256", "witness"):
+        _check_msm(ctx, 0, bases, np_scalars(77, n, kind))
+    _check_msm(ctx, 1, ol.gen_points(1, 3, 600), np_scalars(78, 600, "full256"))
+
+
+def test_msm_pipelined_enqueue_finish_fifo(ctx):
+    """Several MSMs in flight (k16_msm_enqueue x k, then k16_msm_finish x k) return their results in order."""
+    import k16
+    n = 3000
+    bases = ol.gen_points(0, 5, n)
+    d_b = ctx.to_device(bases)
+    sc = [np_scalars(500 + i, n, "full256") for i in range(5)]
+    d_s = [ctx.to_device(s) for s in sc]
+    for d in d_s:
+        ctx.msm_enqueue(k16.G1, d_b, d, n)
+    got = [ctx.msm_finish(k16.G1)[1] for _ in d_s]
+    want = [ol.msm(0, bases, s, nthreads=4)[1] for s in sc]
+    assert got == want
+    with pytest.raises(k16.K16Error):
+        ctx.msm_finish(k16.G1)          # nothing pending

@@ -31,8 +31,9 @@ for kind in kinds:
         iters = 5
         for _ in range(iters):
             ctx.msm_enqueue(0, d_b, d_s, n)
+        for _ in range(iters):
+            ctx.msm_finish(0)
         ms = ctx.timer_stop()
-        ctx.msm_finish(0)
         print("G1 MSM 2^%d %-8s c=%2d : %.3f ms/msm  (%.1f Mpts/s)" % (logn, kind, cbits, ms / iters, n / (ms / iters) / 1e3), flush=True)
         ctx.stats_enable(True)
         ctx.stats_reset()
