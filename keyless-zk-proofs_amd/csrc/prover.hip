@@ -540,36 +540,40 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     // groth16.cpp:281-283
     K16_HIP(ctx, hipStreamWaitEvent(st, p->ev_h, 0));
     if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_H, p->d_a, N))) return rc;
-    if ((rc = k16_msm_finish(ctx, &pi_a, nullptr))) return rc;
-    if ((rc = k16_msm_finish(ctx, &pib1, nullptr))) return rc;
-    if ((rc = k16_msm_finish(ctx, &pi_b, nullptr))) return rc;
-    if ((rc = k16_msm_finish(ctx, &pi_c, nullptr))) return rc;
-    if ((rc = k16_msm_finish(ctx, &pih, nullptr))) return rc;
-    K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
-    K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
-    if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
-
-    // groth16.cpp:325-352 : blinding (host; six single scalar multiplications)
-    G1Xyzz d1 = G1Xyzz::from_aff(p->delta1);
-    pi_a      = h_madd(pi_a, p->alpha1);
-    pi_a      = h_add(pi_a, h_mul(d1, r_std));
-
-    pi_b = h_madd(pi_b, p->beta2);
-    pi_b = h_add(pi_b, h_mul(G2Xyzz::from_aff(p->delta2), s_std));
-
-    pib1 = h_madd(pib1, p->beta1);
-    pib1 = h_add(pib1, h_mul(d1, s_std));
-
-    pi_c = h_add(pi_c, pih);
-    pi_c = h_add(pi_c, h_mul(pi_a, s_std));
-    pi_c = h_add(pi_c, h_mul(pib1, r_std));
+    // groth16.cpp:325-352 : blinding (host; six single scalar multiplications).  Everything that does not
+    // need an MSM result is computed now, while the GPU is busy; the rest right after the MSM it needs.
+    G1Xyzz d1     = G1Xyzz::from_aff(p->delta1);
+    G1Xyzz d1_r   = h_mul(d1, r_std);
+    G1Xyzz d1_s   = h_mul(d1, s_std);
+    G2Xyzz d2_s   = h_mul(G2Xyzz::from_aff(p->delta2), s_std);
     Fr rr, ss;
     memcpy(rr.v, r_std, 32);
     memcpy(ss.v, s_std, 32);
     Fr      rs = to_mont(fmul(rr, ss)); // = r*s mod r in standard form (groth16.cpp:348-349)
     uint8_t rs_b[32];
     memcpy(rs_b, rs.v, 32);
-    pi_c = h_add(pi_c, pneg(h_mul(d1, rs_b)));
+    G1Xyzz d1_rs_neg = pneg(h_mul(d1, rs_b));
+
+    if ((rc = k16_msm_finish(ctx, &pi_a, nullptr))) return rc;
+    pi_a          = h_madd(pi_a, p->alpha1);
+    pi_a          = h_add(pi_a, d1_r);
+    G1Xyzz a_s    = h_mul(pi_a, s_std);
+    if ((rc = k16_msm_finish(ctx, &pib1, nullptr))) return rc;
+    pib1          = h_madd(pib1, p->beta1);
+    pib1          = h_add(pib1, d1_s);
+    G1Xyzz b1_r   = h_mul(pib1, r_std);
+    if ((rc = k16_msm_finish(ctx, &pi_b, nullptr))) return rc;
+    pi_b = h_madd(pi_b, p->beta2);
+    pi_b = h_add(pi_b, d2_s);
+    if ((rc = k16_msm_finish(ctx, &pi_c, nullptr))) return rc;
+    if ((rc = k16_msm_finish(ctx, &pih, nullptr))) return rc;
+    K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
+    K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
+    if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
+    pi_c = h_add(pi_c, pih);
+    pi_c = h_add(pi_c, a_s);
+    pi_c = h_add(pi_c, b1_r);
+    pi_c = h_add(pi_c, d1_rs_neg);
 
     G1Aff A = to_affine(pi_a), Cc = to_affine(pi_c);
     G2Aff B = to_affine(pi_b);
