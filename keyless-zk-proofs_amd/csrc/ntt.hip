@@ -74,53 +74,12 @@ __global__ void __launch_bounds__(256) k_stage(Fr* __restrict__ a, const Fr* __r
     st_fr(&a[k + j + md2], fsub(u, t));
 }
 
-// Fused radix-2^K pass: stages s0+1 .. s0+K of the same DIT network (fft.cpp:197-218) with the tile
-// held in LDS, so the 21 stage launches of a 2^21 transform (21 x 128 MB of HBM traffic) become 3
-// (stages 1-10, 11-16, 17-21).  Element i = hi*2^(s0+K) + mid*2^s0 + lo: a workgroup owns one hi,
+// Fused radix-2^K passes (k_ntt_pass9 below): stages s0+1 .. s0+K of the same DIT network (fft.cpp:197-218)
+// with the tile held in LDS, so the 21 stage launches of a 2^21 transform (21 x 128 MB of HBM traffic)
+// become 3 (stages 1-10, 11-16, 17-21).  Element i = hi*2^(s0+K) + mid*2^s0 + lo: a workgroup owns one hi,
 // T = 2^TL consecutive lo (coalesced 32*T-byte runs) and all 2^K mid; stage s0+t pairs mid with
 // mid ^ 2^(t-1) and uses the twiddle roots[(mid_low*2^s0 + lo) << (S - s0 - t)] -- exactly the
-// reference's root(s, j).  Same field operations in the same dataflow => bit-identical results.
-template <int DUMMY>
-__global__ void __launch_bounds__(256) k_ntt_pass(Fr* __restrict__ a, const Fr* __restrict__ roots, uint32_t s0,
-                                                  uint32_t K, uint32_t TL, uint32_t S)
-{
-    extern __shared__ uint4 ntt_lds[];
-    Fr*            tile  = reinterpret_cast<Fr*>(ntt_lds);
-    const uint32_t T     = 1u << TL;
-    const uint32_t telem = T << K;                 // elements per tile
-    const uint32_t lo_tiles = (1u << s0) >> TL;    // tiles per hi along lo (>= 1)
-    const uint32_t hi    = blockIdx.x / lo_tiles;
-    const uint32_t lo0   = (blockIdx.x % lo_tiles) << TL;
-    const size_t   base  = ((size_t)hi << (s0 + K)) + lo0;
-    for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {
-        const uint32_t mid = e >> TL, tl = e & (T - 1);
-        st_fr(&tile[e], ld_fr(&a[base + ((size_t)mid << s0) + tl]));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // see k16_lds_sync() in msm_kernels.inc
-    __syncthreads();
-    const uint32_t nbf = telem >> 1;
-    for (uint32_t t = 1; t <= K; t++) {
-        const uint32_t half = 1u << (t - 1);
-        for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
-            const uint32_t tl = b & (T - 1), mm = b >> TL;
-            const uint32_t ml = mm & (half - 1), mh = mm >> (t - 1);
-            const uint32_t m0 = (mh << t) + ml, m1 = m0 + half;
-            const size_t   j  = ((size_t)ml << s0) + lo0 + tl;
-            Fr             w  = ld_fr(&roots[j << (S - s0 - t)]);
-            Fr             x1 = tile[(m1 << TL) + tl];
-            Fr             u  = tile[(m0 << TL) + tl];
-            Fr             tt = fmul(w, x1);
-            tile[(m0 << TL) + tl] = fadd(tt, u);
-            tile[(m1 << TL) + tl] = fsub(u, tt);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-    for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {
-        const uint32_t mid = e >> TL, tl = e & (T - 1);
-        st_fr(&a[base + ((size_t)mid << s0) + tl], tile[e]);
-    }
-}
+// reference's root(s, j).  Same field values in the same dataflow => bit-identical results.
 
 // fft.cpp:226-245 : a[i] <-> a[n-i], both scaled by 2^-logn; a[0], a[n/2] scaled in place
 __global__ void __launch_bounds__(256) k_inv_tail(Fr* __restrict__ a, uint32_t logn, Fr scale)

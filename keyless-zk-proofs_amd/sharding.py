@@ -18,17 +18,29 @@ def shard_range(n, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+_BUFS = {}
+
+
 def exchange_and_fold(dist, group, partial_xyzz, device=None):
-    """all_gather every rank's partial MSM result and fold them. Returns (xyzz_bytes, affine_bytes)."""
+    """all_gather every rank's partial MSM result and fold them. Returns (xyzz_bytes, affine_bytes).
+    Buffers are cached per (group, world, device): one pinned staging tensor, one send and one receive
+    tensor, so a step costs two small copies and one all_gather_into_tensor."""
     import torch
 
     nbytes = k16.XYZZ_BYTES[group]
     assert len(partial_xyzz) == nbytes
-    mine = torch.frombuffer(bytearray(partial_xyzz), dtype=torch.uint8)
-    if device is not None:
-        mine = mine.to(device)
     world = dist.get_world_size()
-    bufs = [torch.empty(nbytes, dtype=torch.uint8, device=mine.device) for _ in range(world)]
-    dist.all_gather(bufs, mine)
-    parts = torch.stack(bufs).cpu().numpy()
+    key = (group, world, str(device))
+    if key not in _BUFS:
+        dev = torch.device(device) if device is not None else torch.device("cpu")
+        stage = torch.empty(nbytes, dtype=torch.uint8)
+        if dev.type == "cuda":
+            stage = stage.pin_memory()
+        _BUFS[key] = (stage, torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                      torch.empty(world * nbytes, dtype=torch.uint8, device=dev))
+    stage, send, recv = _BUFS[key]
+    stage.copy_(torch.frombuffer(bytearray(partial_xyzz), dtype=torch.uint8))
+    send.copy_(stage, non_blocking=True)
+    dist.all_gather_into_tensor(recv, send)
+    parts = recv.cpu().numpy().reshape(world, nbytes)
     return k16.points_sum(group, np.ascontiguousarray(parts))
