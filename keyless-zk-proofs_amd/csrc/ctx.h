@@ -51,10 +51,10 @@ struct k16_ctx {
     // slot of the pinned staging buffer and an event recorded after its device-to-host copy, so the host
     // tail of one MSM (conversion + Horner) overlaps the next MSM's kernels
     static constexpr int    PEND_SLOTS = 8;
-    static constexpr size_t SLOT_BYTES = 80 * 1024;
+    static constexpr size_t SLOT_BYTES = 128 * 1024;
     struct Pend {
         int      group = -1;
-        unsigned c = 0, w = 0, nbits = 0;
+        unsigned c = 0, w = 0, nbits = 0, mlog = 0;
         uint64_t n = 0;
         int      slot = 0;
     };
@@ -62,6 +62,7 @@ struct k16_ctx {
     int        pend_head = 0, pend_count = 0; // ring: oldest at pend_head
     hipEvent_t pend_ev[PEND_SLOTS] = {};
     int        enq_slot = 0;                  // staging slot of the MSM being enqueued
+    unsigned   pend_mlog = 0;
     unsigned   pend_nbits = 0;                // written by the kernels' host code for the MSM being enqueued
 
     // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2

@@ -87,6 +87,7 @@ static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const v
                              : k16_msm_enqueue_g2(ctx, d_bases, d_scalars, n, c, prepared);
         if (rc) return rc;
         pd.nbits = ctx->pend_nbits;
+        pd.mlog  = ctx->pend_mlog;
         K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->stream));
     }
     ctx->pend[idx] = pd;
@@ -142,7 +143,7 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
             T[i] = xyzz9_to_canonical(p9);
         }
         G1Xyzz r;
-        horner_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, 3, &r);
+        horner_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G1Aff a = to_affine(r);
@@ -158,7 +159,7 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
                                          fq2n_to_canonical(p9.zzz)};
         }
         G2Xyzz r;
-        horner_host<Fq2>(T.data(), pd.w, pd.c, pd.nbits, 3, &r);
+        horner_host<Fq2>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G2Aff a = to_affine(r);
