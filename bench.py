@@ -113,7 +113,11 @@ def main():
 
     import sharding
 
+    lane = [0]
+
     def enqueue():
+        ctx.set_lane(lane[0])            # alternate the two MSM lanes (stream + workspace): consecutive MSMs overlap
+        lane[0] ^= 1
         ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
 
     def finish():

@@ -95,6 +95,11 @@ int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine);
  * table is passed to k16_msm_enqueue_prepared instead of the zkey-format one. */
 int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out);
 int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_prepared, const void* d_scalars, uint64_t n);
+/* A context has K16_MSM_LANES independent MSM lanes (HIP stream + workspace).  The next k16_msm_enqueue* uses the
+ * selected lane; MSMs on different lanes may overlap on the GPU (their inputs must already be complete: uploads
+ * through k16_h2d are).  k16_msm_finish still returns results in enqueue order.  Default lane 0. */
+#define K16_MSM_LANES 2
+int k16_msm_set_lane(k16_ctx* ctx, int lane);
 /* override the window size chosen for the next MSMs (0 = automatic) */
 int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c);
 

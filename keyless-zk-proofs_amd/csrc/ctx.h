@@ -41,8 +41,21 @@ struct k16_ctx {
     unsigned    forced_c = 0;
 
     // MSM workspace (grown on demand, reused across calls)
-    k16_devbuf ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
-        ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
+    // MSM lanes: independent (stream, workspace) pairs.  MSMs enqueued on different lanes may overlap on the
+    // GPU -- the fold / weighted-sum stages are latency-bound chains on few lanes and leave most CUs idle, so a
+    // second MSM's sort or accumulation fills them.  Lane 0's stream is also ctx->stream.
+    static constexpr int N_LANES = 2;
+    struct Lane {
+        hipStream_t stream = nullptr;
+        k16_devbuf  ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
+            ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
+        // bucket sort still valid in this lane's workspace (same scalars, n, c): see reuse_sort
+        const void* sorted_scalars = nullptr;
+        uint64_t    sorted_n = 0;
+        unsigned    sorted_c = 0;
+    };
+    Lane lanes[N_LANES];
+    int  cur_lane = 0; // lane of the next k16_msm_enqueue*
     void* pinned = nullptr; // small pinned host staging buffer
     size_t pinned_bytes = 0;
 
@@ -67,9 +80,6 @@ struct k16_ctx {
 
     // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2
     // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)
-    const void* sorted_scalars = nullptr;
-    uint64_t    sorted_n = 0;
-    unsigned    sorted_c = 0;
     bool        reuse_sort = false;
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;

@@ -9,7 +9,7 @@ int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes)
 {
     if (b.bytes >= bytes) return K16_OK;
     if (b.p) {
-        K16_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        K16_HIP(ctx, hipDeviceSynchronize()); // any lane may still be using the old buffer
         K16_HIP(ctx, hipFree(b.p));
         b.p     = nullptr;
         b.bytes = 0;
@@ -29,7 +29,11 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (hipSetDevice(device) != hipSuccess) return K16_ERR_NO_DEVICE;
     k16_ctx* c = new k16_ctx();
     c->device  = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+    bool lanes_ok = true;
+    for (int i = 0; i < k16_ctx::N_LANES; i++)
+        lanes_ok = lanes_ok && hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess;
+    c->stream = c->lanes[0].stream;
+    if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
         delete c;
         return K16_ERR_NO_DEVICE;
@@ -53,11 +57,14 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    k16_devbuf* bufs[] = {&c->ws_counts, &c->ws_offsets, &c->ws_cursor, &c->ws_sorted, &c->ws_segoff,
-                          &c->ws_segbucket, &c->ws_partial, &c->ws_big, &c->ws_misc, &c->ws_lvl_a,
-                          &c->ws_lvl_b, &c->ws_lvl_c, &c->ws_lvl_d, &c->ws_scan, &c->ws_conv};
-    for (auto* b : bufs)
-        if (b->p) (void)hipFree(b->p);
+    (void)hipDeviceSynchronize();
+    for (auto& L : c->lanes) {
+        k16_devbuf* bufs[] = {&L.ws_counts, &L.ws_offsets, &L.ws_cursor, &L.ws_sorted, &L.ws_segoff, &L.ws_segbucket,
+                              &L.ws_partial, &L.ws_big, &L.ws_misc, &L.ws_lvl_a, &L.ws_lvl_b, &L.ws_lvl_c,
+                              &L.ws_lvl_d, &L.ws_scan, &L.ws_conv};
+        for (auto* b : bufs)
+            if (b->p) (void)hipFree(b->p);
+    }
     for (auto& kv : c->ntt_tables)
         if (kv.second.roots) (void)hipFree(kv.second.roots);
     for (auto& kv : c->ntt_tables)
@@ -68,7 +75,8 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     (void)hipEventDestroy(c->ev_a);
     (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ks_pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(c->stream);
+    for (auto& L : c->lanes)
+        if (L.stream) (void)hipStreamDestroy(L.stream);
     delete c;
 }
 
@@ -78,7 +86,8 @@ extern "C" void*       k16_stream(k16_ctx* c) { return c ? (void*)c->stream : nu
 extern "C" int k16_sync(k16_ctx* c)
 {
     if (!c) return K16_ERR_ARG;
-    K16_HIP(c, hipStreamSynchronize(c->stream));
+    K16_HIP(c, hipSetDevice(c->device));
+    K16_HIP(c, hipDeviceSynchronize());
     return K16_OK;
 }
 extern "C" int k16_dev_alloc(k16_ctx* c, size_t bytes, void** dptr)
@@ -91,7 +100,7 @@ extern "C" int k16_dev_alloc(k16_ctx* c, size_t bytes, void** dptr)
 extern "C" int k16_dev_free(k16_ctx* c, void* dptr)
 {
     if (!c) return K16_ERR_ARG;
-    K16_HIP(c, hipStreamSynchronize(c->stream));
+    K16_HIP(c, hipDeviceSynchronize());
     K16_HIP(c, hipFree(dptr));
     return K16_OK;
 }

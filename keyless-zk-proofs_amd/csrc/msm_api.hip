@@ -10,8 +10,8 @@ using namespace k16;
 
 int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
 int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
-int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out);
-int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out);
+int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out, hipStream_t st);
+int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out, hipStream_t st);
 
 namespace {
 constexpr unsigned MAX_C = 16;
@@ -53,6 +53,13 @@ void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsig
 
 } // namespace
 
+extern "C" int k16_msm_set_lane(k16_ctx* ctx, int lane)
+{
+    if (!ctx || lane < 0 || lane >= k16_ctx::N_LANES) return K16_ERR_ARG;
+    ctx->cur_lane = lane;
+    return K16_OK;
+}
+
 extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
 {
     if (!ctx) return K16_ERR_ARG;
@@ -88,7 +95,7 @@ static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const v
         if (rc) return rc;
         pd.nbits = ctx->pend_nbits;
         pd.mlog  = ctx->pend_mlog;
-        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->stream));
+        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->lanes[ctx->cur_lane].stream));
     }
     ctx->pend[idx] = pd;
     ctx->pend_count++;
@@ -107,8 +114,8 @@ extern "C" int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_p
 extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out)
 {
     if (!ctx || (group != K16_G1 && group != K16_G2) || (n && (!d_bases || !d_out))) return K16_ERR_ARG;
-    if (group == K16_G1) return k16_msm_prepare_g1(ctx, d_bases, n, d_out);
-    return k16_msm_prepare_g2(ctx, d_bases, n, d_out);
+    if (group == K16_G1) return k16_msm_prepare_g1(ctx, d_bases, n, d_out, nullptr);
+    return k16_msm_prepare_g2(ctx, d_bases, n, d_out, nullptr);
 }
 
 extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
@@ -197,8 +204,9 @@ extern "C" int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const 
         ctx->err = "hipMemcpyAsync h2d";
         rc       = K16_ERR_HIP;
     }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = K16_ERR_HIP; // uploads ran on lane 0's stream
     if (!rc) rc = k16_msm(ctx, group, db, ds, n, h_out_xyzz, h_out_affine);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipDeviceSynchronize();
     (void)hipFree(db);
     (void)hipFree(ds);
     return rc;

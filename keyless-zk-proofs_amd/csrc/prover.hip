@@ -526,20 +526,33 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     if (p->n_vars < (1u << 17)) wc = 0; // small circuits: automatic
     // All five MSMs are enqueued back to back; their host tails (conversion + Horner, ~0.3 ms each, ~1.2 ms for
     // G2) run while later MSMs occupy the GPU.
+    // Lane 0: A, B1, B2 (one shared sort).  Lane 1: C, then H once the polynomial chain is done.  The fold and
+    // weighted-sum stages of one lane leave most CUs idle; the other lane's kernels fill them.
+    struct LaneReset {
+        k16_ctx* c;
+        ~LaneReset() { c->cur_lane = 0; }
+    } lane_reset{ctx};
+    hipStream_t s1 = ctx->lanes[1].stream;
+    K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_w, 0)); // witness upload (lane 0's stream)
     {
         ForcedC fc(ctx, wc);
+        ctx->cur_lane = 0;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars))) return rc;
+        ctx->cur_lane = 1;
+        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1),
+                                           (uint64_t)p->n_vars - p->n_public - 1)))
+            return rc;
+        ctx->cur_lane   = 0;
         ctx->reuse_sort = true;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
         ctx->reuse_sort = true;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1),
-                                           (uint64_t)p->n_vars - p->n_public - 1)))
-            return rc;
     }
     // groth16.cpp:281-283
-    K16_HIP(ctx, hipStreamWaitEvent(st, p->ev_h, 0));
+    ctx->cur_lane = 1;
+    K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_h, 0));
     if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_H, p->d_a, N))) return rc;
+    ctx->cur_lane = 0;
     // groth16.cpp:325-352 : blinding (host; six single scalar multiplications).  Everything that does not
     // need an MSM result is computed now, while the GPU is busy; the rest right after the MSM it needs.
     G1Xyzz d1     = G1Xyzz::from_aff(p->delta1);
@@ -558,6 +571,7 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     pi_a          = h_madd(pi_a, p->alpha1);
     pi_a          = h_add(pi_a, d1_r);
     G1Xyzz a_s    = h_mul(pi_a, s_std);
+    if ((rc = k16_msm_finish(ctx, &pi_c, nullptr))) return rc; // enqueue order: A, C, B1, B2, H
     if ((rc = k16_msm_finish(ctx, &pib1, nullptr))) return rc;
     pib1          = h_madd(pib1, p->beta1);
     pib1          = h_add(pib1, d1_s);
@@ -565,8 +579,8 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     if ((rc = k16_msm_finish(ctx, &pi_b, nullptr))) return rc;
     pi_b = h_madd(pi_b, p->beta2);
     pi_b = h_add(pi_b, d2_s);
-    if ((rc = k16_msm_finish(ctx, &pi_c, nullptr))) return rc;
     if ((rc = k16_msm_finish(ctx, &pih, nullptr))) return rc;
+    K16_HIP(ctx, hipStreamWaitEvent(st, ctx->pend_ev[(ctx->pend_head + k16_ctx::PEND_SLOTS - 1) % k16_ctx::PEND_SLOTS], 0));
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));

@@ -25,7 +25,7 @@ SYMBOLS = [
     "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
-    "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_set_window_bits", "k16_points_sum",
+    "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
@@ -72,6 +72,7 @@ def load():
     L.k16_msm_bases_prepare.argtypes = [vp, i32, vp, u64, vp]
     L.k16_msm_enqueue_prepared.argtypes = [vp, i32, vp, vp, u64]
     L.k16_msm_set_window_bits.argtypes = [vp, u32]
+    L.k16_msm_set_lane.argtypes = [vp, i32]
     L.k16_points_sum.argtypes = [i32, vp, u64, vp, vp]
     L.k16_ntt.argtypes = [vp, vp, u64, u64, i32]
     L.k16_ntt_host.argtypes = [vp, vp, u64, u64, i32]
@@ -169,6 +170,9 @@ class Context:
         n, ms = C.c_uint64(), C.c_double()
         self._chk(self.L.k16_kernel_stats_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def set_lane(self, lane):
+        self._chk(self.L.k16_msm_set_lane(self.h, lane))
 
     def set_window_bits(self, c):
         self._chk(self.L.k16_msm_set_window_bits(self.h, c))
