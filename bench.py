@@ -4,8 +4,10 @@
 Workload (BASELINE.json configs[1]): BN254 G1 Pippenger MSM, 2^20 points, uniform random scalars in
 [0, r), bases (i+1)*G -- all resident in HBM before the timed region.  One "step" = one complete MSM
 (digits -> bucket sort -> bucket accumulation -> weighted bucket reduction -> Horner combine ->
-XYZZ result on the host).  Steps are software-pipelined two deep: the kernels of step k+1 are enqueued
-before the host tail (0.25 ms) of step k runs; the timed region still contains exactly K complete MSMs.
+XYZZ result on the host).  Steps are software-pipelined three deep over the context's MSM lanes (stream +
+workspace each): the kernels of steps k+1, k+2 are enqueued before step k is finished, so the latency-bound
+fold / reduction stages of one MSM overlap the next one's sort and accumulation and the 0.25 ms host tail is
+hidden; the timed region still contains exactly K complete MSMs, each fully reduced to one point.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -116,8 +118,8 @@ def main():
     lane = [0]
 
     def enqueue():
-        ctx.set_lane(lane[0])            # alternate the two MSM lanes (stream + workspace): consecutive MSMs overlap
-        lane[0] ^= 1
+        ctx.set_lane(lane[0])            # cycle the MSM lanes (stream + workspace): consecutive MSMs overlap
+        lane[0] = (lane[0] + 1) % depth
         ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
 
     def finish():
@@ -126,12 +128,15 @@ def main():
             xyzz, _ = sharding.exchange_and_fold(dist, k16.G1, xyzz, device="cuda")
         return xyzz
 
+    depth = max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "3")), 3))
+
     def run(steps):
-        """steps complete MSMs; MSM k+1 is enqueued before the host tail of MSM k runs (two in flight)."""
+        """steps complete MSMs, `depth` of them in flight: MSM k+depth-1 is enqueued before MSM k is finished."""
         res = None
-        enqueue()
+        for k in range(min(depth - 1, steps)):
+            enqueue()
         for k in range(steps):
-            if k + 1 < steps:
+            if k + depth - 1 < steps:
                 enqueue()
             res = finish()
         return res

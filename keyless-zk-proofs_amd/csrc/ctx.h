@@ -44,7 +44,7 @@ struct k16_ctx {
     // MSM lanes: independent (stream, workspace) pairs.  MSMs enqueued on different lanes may overlap on the
     // GPU -- the fold / weighted-sum stages are latency-bound chains on few lanes and leave most CUs idle, so a
     // second MSM's sort or accumulation fills them.  Lane 0's stream is also ctx->stream.
-    static constexpr int N_LANES = 2;
+    static constexpr int N_LANES = 3;
     struct Lane {
         hipStream_t stream = nullptr;
         k16_devbuf  ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
