@@ -119,7 +119,7 @@ def main():
 
     def enqueue():
         ctx.set_lane(lane[0])            # cycle the MSM lanes (stream + workspace): consecutive MSMs overlap
-        lane[0] = (lane[0] + 1) % depth
+        lane[0] = (lane[0] + 1) % depth_cell[0]
         ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
 
     def finish():
@@ -128,10 +128,11 @@ def main():
             xyzz, _ = sharding.exchange_and_fold(dist, k16.G1, xyzz, device="cuda")
         return xyzz
 
-    depth = max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "3")), 3))
+    depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "3")), 3))]
 
     def run(steps):
         """steps complete MSMs, `depth` of them in flight: MSM k+depth-1 is enqueued before MSM k is finished."""
+        depth = depth_cell[0]
         res = None
         for k in range(min(depth - 1, steps)):
             enqueue()
@@ -158,6 +159,14 @@ def main():
     launches, acc_ms = ctx.stats_get("msm_accumulate")
     stage_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
                 for k in ("msm_sort", "msm_accumulate", "msm_fold", "msm_reduce")}
+    # the same kernel without a neighbour on the GPU (one MSM at a time), for reference next to the live figure
+    ctx.stats_reset()
+    saved_depth = depth_cell[0]
+    depth_cell[0] = 1
+    lane[0] = 0
+    run(3)
+    depth_cell[0] = saved_depth
+    iso_launches, iso_ms = ctx.stats_get("msm_accumulate")
     ctx.stats_enable(False)
 
     if dist is not None:
@@ -206,7 +215,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "kernel_ms": kern_s * 1e3,
-                "note": "integer-multiply-issue bound in practice; see DESIGN.md (modmul-rate view)",
+                "kernel_ms_isolated": iso_ms / max(iso_launches, 1),
+                "frac_isolated": (n * ALGO_BYTES_PER_POINT) / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                 if iso_ms > 0 else None,
+                "note": "kernel_ms is the live average inside the timed region, where up to three MSMs share the GPU "
+                        "(lanes); kernel_ms_isolated is the same kernel with one MSM at a time. Integer-multiply-issue "
+                        "bound in practice; see DESIGN.md (modmul-rate view)",
             },
             "stage_ms": stage_ms,
         }
