@@ -117,4 +117,7 @@ struct k16_stat_scope {
 
 // host-side helpers implemented in msm.hip
 int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out);
+// packed9: bit 0 = data is in the packed R' domain, bit 1 = input already bit-reversed, bit 2 = skip the inverse tail
 int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st, int packed9);
+int k16_ntt_tail_shift_bitrev(k16_ctx* ctx, const k16::Fr* src, k16::Fr* dst, uint64_t n, k16_ntt_table* tab,
+                              uint32_t stride_log, hipStream_t st);

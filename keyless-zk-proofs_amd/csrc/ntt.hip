@@ -251,8 +251,10 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
     }
     uint32_t       logn = ilog2_u64(n);
     k16_stat_scope ss(ctx, "ntt", st);
+    const bool skip_bitrev = (packed9 & 2) != 0, skip_tail = (packed9 & 4) != 0;
+    packed9 &= 1;
     if (logn >= 1) {
-        hipLaunchKernelGGL(k_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, logn);
+        if (!skip_bitrev) hipLaunchKernelGGL(k_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, logn);
         if (!packed9 && getenv("K16_NTT_UNFUSED")) {
             for (uint32_t s = 1; s <= logn; s++)
                 hipLaunchKernelGGL(k_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, d_a, tab->roots, logn,
@@ -279,7 +281,7 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
             }
         }
     }
-    if (inverse) {
+    if (inverse && !skip_tail) {
         if (logn == 0) {
             // n == 1: fft.cpp:243-244 scales a[0] twice (a[0] and a[n>>1] alias) by 2^0 = 1: identity
         } else if (packed9) {
@@ -290,6 +292,31 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
                                logn, tab->pow2inv[logn]);
         }
     }
+    K16_HIP(ctx, hipGetLastError());
+    return K16_OK;
+}
+
+// Prover-internal fusion of three permutation / scaling passes between the inverse and the forward transform
+// of the coset chain (groth16.cpp:172-262): iNTT tail (fft.cpp:226-245: y[i] = X[(n-i) mod n] * 2^-k), coset
+// shift (y[i] *= root(k+1, i)) and the bit reversal that opens the next forward transform, out of place:
+//     dst[bitrev(i)] = src[(n - i) mod n] * 2^-k * root(k+1, i)
+__global__ void __launch_bounds__(256) k_tail_shift_bitrev9(const Fr* __restrict__ src, Fr* __restrict__ dst, uint32_t logn,
+                                                            Fr9 scale, const Fr* __restrict__ roots9, uint32_t stride_log)
+{
+    const uint32_t n = 1u << logn;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t from = (n - i) & (n - 1);
+    Fr9            v    = frmul9(frmul9(ld_r9(&src[from]), scale), ld_r9(&roots9[(size_t)i << stride_log]));
+    const uint32_t to   = logn ? (__brev(i) >> (32 - logn)) : 0u;
+    st_r9(&dst[to], v);
+}
+int k16_ntt_tail_shift_bitrev(k16_ctx* ctx, const k16::Fr* src, k16::Fr* dst, uint64_t n, k16_ntt_table* tab,
+                              uint32_t stride_log, hipStream_t st)
+{
+    const uint32_t logn = ilog2_u64(n);
+    hipLaunchKernelGGL(k_tail_shift_bitrev9, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, logn,
+                       tab->pow2inv9[logn], tab->roots9, stride_log);
     K16_HIP(ctx, hipGetLastError());
     return K16_OK;
 }

@@ -128,14 +128,17 @@ __device__ __forceinline__ void st_r9(Fr* p, const Fr9& v)
 // 256-bit atomics / spinlocks are needed.  Field addition is exact, so the summation order is free.
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ wire,
                                               const Fr* __restrict__ coef9, const Fr* __restrict__ wtns,
-                                              Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N)
+                                              Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N, uint32_t logN)
 {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * N) return;
     uint32_t lo = row_ptr[t], hi = row_ptr[t + 1];
     Fr9      acc = fq9_zero();
     for (uint32_t k = lo; k < hi; k++) acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[k]]), ld_r9(&coef9[k])));
-    st_r9(t < N ? &a[t] : &b[t - N], acc);
+    // rows are stored at their bit-reversed position: the inverse transforms that follow skip their own reversal
+    const uint32_t row = t < N ? t : t - N;
+    const uint32_t pos = logN ? (__brev(row) >> (32 - logN)) : 0u;
+    st_r9(t < N ? &a[pos] : &b[pos], acc);
 }
 // groth16.cpp:160-167
 __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __restrict__ a, const Fr* __restrict__ b,
@@ -152,11 +155,11 @@ __global__ void __launch_bounds__(256) k_shift(Fr* __restrict__ x, const Fr* __r
     if (i < N) st_r9(&x[i], frmul9(ld_r9(&x[i]), ld_r9(&roots9[(size_t)i << stride_log])));
 }
 // groth16.cpp:266-275 : a = fromMontgomery(a*b - c)  (standard form, canonical: the H MSM's scalars)
-__global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ a, const Fr* __restrict__ b,
-                                                  const Fr* __restrict__ c, uint32_t N)
+__global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr* __restrict__ a,
+                                                  const Fr* __restrict__ b, const Fr* __restrict__ c, uint32_t N)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) st_fr(&a[i], fr9_to_standard(frsub9(frmul9(ld_r9(&a[i]), ld_r9(&b[i])), ld_r9(&c[i]))));
+    if (i < N) st_fr(&out[i], fr9_to_standard(frsub9(frmul9(ld_r9(&a[i]), ld_r9(&b[i])), ld_r9(&c[i]))));
 }
 
 // ---------------------------------------------------------------- host helpers
@@ -239,7 +242,7 @@ struct k16_prover {
     uint32_t *d_rowptr = nullptr, *d_wire = nullptr;
     Fr*       d_coef  = nullptr;
     // per-proof buffers
-    Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+    Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr;
     k16_ntt_table* ntt = nullptr;
     hipStream_t    st2 = nullptr;          // polynomial chain (SpMV, NTTs) runs beside the witness MSMs
     hipEvent_t     ev_w = nullptr, ev_h = nullptr;
@@ -250,7 +253,7 @@ static void prover_free(k16_prover* p)
 {
     if (!p) return;
     void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_B2, p->d_rowptr, p->d_wire, p->d_coef,
-                    p->d_wtns, p->d_a, p->d_b, p->d_c};
+                    p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->st2) (void)hipStreamDestroy(p->st2);
@@ -390,6 +393,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_a, (size_t)N * 32), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_b, (size_t)N * 32), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_c, (size_t)N * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_t, (size_t)N * 32), p);
     hipStream_t st = ctx->stream;
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_A, bv.sec[5].p, nv * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_B1, bv.sec[6].p, nv * 64, hipMemcpyHostToDevice, st), p);
@@ -495,16 +499,21 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     K16_HIP(ctx, hipStreamWaitEvent(s2, p->ev_w, 0));
     const unsigned gN = (N + 255) / 256;
     hipLaunchKernelGGL(k_spmv, dim3((2 * N + 255) / 256), dim3(256), 0, s2, p->d_rowptr, p->d_wire, p->d_coef,
-                       p->d_wtns, p->d_a, p->d_b, N);
-    hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N);
-    Fr* vec[3] = {p->d_a, p->d_b, p->d_c};
+                       p->d_wtns, p->d_a, p->d_b, N, p->logN);
+    hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N); // elementwise: same permutation
+    // x -> iNTT passes (input already bit-reversed, tail deferred) -> [tail, coset shift, bit reversal] fused and
+    // out of place -> NTT passes.  Buffers rotate: a -> t, b -> a, c -> b.
+    Fr* src[3] = {p->d_a, p->d_b, p->d_c};
+    Fr* dst[3] = {p->d_t, p->d_a, p->d_b};
     for (int k = 0; k < 3; k++) {
-        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 1, s2, 1))) return rc;
-        hipLaunchKernelGGL(k_shift, dim3(gN), dim3(256), 0, s2, vec[k], p->ntt->roots9, N, p->ntt->s - p->logN - 1);
-        if ((rc = k16_ntt_enqueue(ctx, vec[k], N, p->ntt, 0, s2, 1))) return rc;
+        if ((rc = k16_ntt_enqueue(ctx, src[k], N, p->ntt, 1, s2, 1 | 2 | 4))) return rc;
+        if ((rc = k16_ntt_tail_shift_bitrev(ctx, src[k], dst[k], N, p->ntt, p->ntt->s - p->logN - 1, s2))) return rc;
+        if ((rc = k16_ntt_enqueue(ctx, dst[k], N, p->ntt, 0, s2, 1 | 2))) return rc;
     }
-    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_b, p->d_c, N);
+    // A in d_t, B in d_a, C in d_b; the H scalars go to d_c (free now), which then becomes the prover's "a" buffer
+    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_t, p->d_a, p->d_b, N);
     K16_HIP(ctx, hipGetLastError());
+    std::swap(p->d_a, p->d_c);
     K16_HIP(ctx, hipEventRecord(p->ev_h, s2));
 
     // groth16.cpp:88-112 : the four witness MSMs.  A, B1 and B2 share their scalars (the witness), so the
