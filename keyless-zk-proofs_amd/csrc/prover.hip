@@ -147,13 +147,6 @@ __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __res
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) st_r9(&c[i], frmul9(ld_r9(&a[i]), ld_r9(&b[i])));
 }
-// groth16.cpp:182-190 : x[i] *= root(log2N + 1, i) = roots[i << (S - log2N - 1)]
-__global__ void __launch_bounds__(256) k_shift(Fr* __restrict__ x, const Fr* __restrict__ roots9, uint32_t N,
-                                               uint32_t stride_log)
-{
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) st_r9(&x[i], frmul9(ld_r9(&x[i]), ld_r9(&roots9[(size_t)i << stride_log])));
-}
 // groth16.cpp:266-275 : a = fromMontgomery(a*b - c)  (standard form, canonical: the H MSM's scalars)
 __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr* __restrict__ a,
                                                   const Fr* __restrict__ b, const Fr* __restrict__ c, uint32_t N)
