@@ -124,7 +124,75 @@ K16_HD Fq9 fmul9_t(const Fq9& a, const Fq9& b)
     return r;
 }
 K16_HD Fq9 fmul9(const Fq9& a, const Fq9& b) { return fmul9_t<Fq9C>(a, b); }
-K16_HD Fq9 fsqr9(const Fq9& a) { return fmul9(a, a); }
+
+// a^2 / R': the 36 off-diagonal products are formed once against the doubled limbs (2*a_i < 2^30), so a
+// squaring is 45 + 81 multiply-adds instead of 162.  Column bound: 4 * 2^59 + 2^58 + 9 * 2^58 < 2^63.
+template <class C>
+K16_HD Fq9 fsqr9_t(const Fq9& a)
+{
+    uint32_t m[9], a2[9];
+    Fq9      r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a2[i] = a.l[i] << 1;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc2 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            if (i < j) acc += (uint64_t)a2[i] * a.l[j];
+            if (i == j) acc += (uint64_t)a.l[i] * a.l[i];
+            if (k >= 9 || i < k) acc2 += (uint64_t)m[i] * C::P[j];
+        }
+        acc += acc2;
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * C::NP) & C::MASK;
+            acc += (uint64_t)m[k] * C::P[0];
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & C::MASK;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+K16_HD Fq9 fsqr9(const Fq9& a) { return fsqr9_t<Fq9C>(a); }
+
+// (a*b + c*d) / R' with ONE Montgomery reduction: < p * (1 + (A*B + C*D)/169).  Column bound: 27 * 2^58 < 2^63.
+template <class C>
+K16_HD Fq9 fmul9_sum2_t(const Fq9& a, const Fq9& b, const Fq9& c, const Fq9& d)
+{
+    uint32_t m[9];
+    Fq9      r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc2 = 0, acc3 = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            acc += (uint64_t)a.l[i] * b.l[j];
+            acc3 += (uint64_t)c.l[i] * d.l[j];
+            if (k >= 9 || i < k) acc2 += (uint64_t)m[i] * C::P[j];
+        }
+        acc += acc2 + acc3;
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * C::NP) & C::MASK;
+            acc += (uint64_t)m[k] * C::P[0];
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & C::MASK;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+K16_HD Fq9 fmul9_sum2(const Fq9& a, const Fq9& b, const Fq9& c, const Fq9& d) { return fmul9_sum2_t<Fq9C>(a, b, c, d); }
 
 // a + b (bound A + B); limbs renormalised
 K16_HD Fq9 fadd9(const Fq9& a, const Fq9& b)
@@ -289,7 +357,7 @@ K16_HD Xyzz9 pdbl_aff9(const Aff9& p)
     Fq9 M  = fsqr9(p.x);                            // 4  -> 2
     M      = fadd9(fdbl9(M), M);                    // 6
     Fq9 X3 = fsub9<4>(fsqr9(M), fdbl9(S));          // 36 -> 2 ; - 2S (<4) -> 6
-    Fq9 Y3 = fsub9<2>(fmul9(M, fsub9<8>(S, X3)), fmul9(W, p.y)); // (S - X3 + 8p) < 10 ; 6*10 -> 2 ; W*y 4 -> 2 ; -> 4
+    Fq9 Y3 = fmul9_sum2(M, fsub9<8>(S, X3), W, fsub9<2>(fq9_zero(), p.y)); // M*(S-X3) + W*(-y): 6*10 + 2*2 -> 2
     return Xyzz9{X3, Y3, V, W};
 }
 // curve.cpp:340-396
@@ -303,7 +371,7 @@ K16_HD Xyzz9 pdbl9(const Xyzz9& p)
     Fq9 M  = fsqr9(p.x);                            // 64 -> 2
     M      = fadd9(fdbl9(M), M);                    // 6
     Fq9 X3 = fsub9<4>(fsqr9(M), fdbl9(S));          // < 6
-    Fq9 Y3 = fsub9<2>(fmul9(M, fsub9<8>(S, X3)), fmul9(W, p.y)); // 6*10 ; 2*4 ; -> 4
+    Fq9 Y3 = fmul9_sum2(M, fsub9<8>(S, X3), W, fsub9<4>(fq9_zero(), p.y)); // 6*10 + 2*4 -> 2
     return Xyzz9{X3, Y3, fmul9(V, p.zz), fmul9(W, p.zzz)};
 }
 // curve.cpp:185-250
@@ -320,8 +388,25 @@ K16_HD Xyzz9 padd_mixed9(const Xyzz9& p1, const Aff9& p2)
     Fq9 PPP = fmul9(P, PP);                         // 20 -> 2
     Fq9 Q   = fmul9(p1.x, PP);                      // 16 -> 2
     Fq9 X3  = fsub9<4>(fsub9<2>(fsqr9(R), PPP), fdbl9(Q)); // 36 -> 2 ; -PPP -> 4 ; -2Q -> 8
-    Fq9 Y3  = fsub9<2>(fmul9(fsub9<8>(Q, X3), R), fmul9(p1.y, PPP)); // (Q - X3 + 8p) < 10 ; 10*6 -> 2 ; 4*2 -> 2 ; -> 4
+    // Y3 = (Q - X3)*R - Y1*PPP as ONE reduction of two products: (Q - X3 + 8p) < 10, R < 6, (4p - Y1) <= 4, PPP < 2 -> 68/169
+    Fq9 Y3  = fmul9_sum2(fsub9<8>(Q, X3), R, fsub9<4>(fq9_zero(), p1.y), PPP); // < 2
     return Xyzz9{X3, Y3, fmul9(p1.zz, PP), fmul9(p1.zzz, PPP)};
+}
+// affine + affine -> XYZZ: the mixed addition above with ZZ1 = ZZZ1 = 1 (U2 = x2, S2 = y2, ZZ3 = PP, ZZZ3 = PPP), i.e.
+// the same values as padd_mixed9(from_aff(a), b) for 4 multiplications less.  First add of every bucket segment.
+K16_HD Xyzz9 padd_aff_aff9(const Aff9& a, const Aff9& b)
+{
+    if (a.is_zero()) return Xyzz9::from_aff(b);
+    if (b.is_zero()) return Xyzz9::from_aff(a);
+    Fq9 P = fsub9<2>(b.x, a.x);                     // 4
+    Fq9 R = fsub9<2>(b.y, a.y);                     // 4
+    if (fq9_is_zero_mod_p<4>(P) && fq9_is_zero_mod_p<4>(R)) return pdbl_aff9(b);
+    Fq9 PP  = fsqr9(P);                             // 16 -> 2
+    Fq9 PPP = fmul9(P, PP);                         // 8 -> 2
+    Fq9 Q   = fmul9(a.x, PP);                       // 4 -> 2
+    Fq9 X3  = fsub9<4>(fsub9<2>(fsqr9(R), PPP), fdbl9(Q)); // 8
+    Fq9 Y3  = fmul9_sum2(fsub9<8>(Q, X3), R, fsub9<2>(fq9_zero(), a.y), PPP); // 10*4 + 2*2 -> 2
+    return Xyzz9{X3, Y3, PP, PPP};
 }
 // curve.cpp:91-166
 K16_HD Xyzz9 padd9(const Xyzz9& p1, const Xyzz9& p2)
@@ -339,7 +424,7 @@ K16_HD Xyzz9 padd9(const Xyzz9& p1, const Xyzz9& p2)
     Fq9 PPP = fmul9(P, PP);
     Fq9 Q   = fmul9(U1, PP);
     Fq9 X3  = fsub9<4>(fsub9<2>(fsqr9(R), PPP), fdbl9(Q)); // 8
-    Fq9 Y3  = fsub9<2>(fmul9(fsub9<8>(Q, X3), R), fmul9(S1, PPP)); // 10*4 ; -> 4
+    Fq9 Y3  = fmul9_sum2(fsub9<8>(Q, X3), R, fsub9<2>(fq9_zero(), S1), PPP); // 10*4 + 2*2 -> 2
     return Xyzz9{X3, Y3, fmul9(fmul9(p1.zz, p2.zz), PP), fmul9(fmul9(p1.zzz, p2.zzz), PPP)};
 }
 

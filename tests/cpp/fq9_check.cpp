@@ -80,6 +80,13 @@ int main()
         CHECK(fq9_to_fq(fsub9<8>(A, B)) == fsub(a, b), "sub8");
         Fq9 big = fadd9(fadd9(fadd9(A, B), fadd9(A, B)), fadd9(A, A)); // < 12p
         CHECK(fq9_to_fq(fmul9(big, B)) == fmul(fadd(fadd(fadd(a, b), fadd(a, b)), fadd(a, a)), b), "mul with lazy operand");
+        CHECK(fq9_to_fq(fsqr9(A)) == fmul(a, a) && below_kp(fsqr9(A), 2) && normalised(fsqr9(A)), "sqr");
+        CHECK(fq9_to_fq(fsqr9(big)) == fmul(fadd(fadd(fadd(a, b), fadd(a, b)), fadd(a, a)), fadd(fadd(fadd(a, b), fadd(a, b)), fadd(a, a))) && below_kp(fsqr9(big), 2), "sqr of a lazy operand (< 12p)");
+        {
+            Fq9 s2 = fmul9_sum2(big, fadd9(A, A), fsub9<4>(fq9_zero(), B), A); // 12*2... bounds 12*4 + 4*2 = 56
+            Fq  w  = fsub(fmul(fadd(fadd(fadd(a, b), fadd(a, b)), fadd(a, a)), fadd(a, a)), fmul(b, a));
+            CHECK(fq9_to_fq(s2) == w && below_kp(s2, 2) && normalised(s2), "a*b + c*d with one reduction");
+        }
         CHECK(fq9_is_zero_mod_p<10>(fsub9<8>(A, A)), "x - x == 0 mod p");
         CHECK(fq9_is_zero_mod_p<4>(A) == a.is_zero(), "is_zero");
     }
@@ -125,6 +132,16 @@ int main()
             CHECK(same_point_repr(n2, c2), "XYZZ (second accumulator)");
         }
     }
+    // affine + affine (first add of a bucket segment): same XYZZ values as the mixed add from from_aff
+    for (int i = 0; i < NP; i++)
+        for (int k = 0; k < NP; k++) {
+            G1Xyzz w = padd_mixed(G1Xyzz::from_aff(tab[i]), tab[k]);
+            Xyzz9  n = padd_aff_aff9(tab9[i], tab9[k]);
+            CHECK(pt_bounds_ok(n), "aff+aff bounds");
+            CHECK(same_point_repr(n, w), "aff+aff == madd(from_aff)");
+            G1Aff ng = pneg(tab[k]);
+            if (i == k && k != 7) CHECK(padd_aff_aff9(tab9[i], aff9_from_canonical(ng)).is_zero(), "aff + (-aff)");
+        }
     // acc == table point -> doubling branch of the mixed add; acc == -table point -> infinity
     for (int k = 0; k < NP; k++) {
         if (k == 7) continue;
