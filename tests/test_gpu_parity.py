@@ -337,3 +337,59 @@ def test_msm_pipelined_enqueue_finish_fifo(ctx):
     assert got == want
     with pytest.raises(k16.K16Error):
         ctx.msm_finish(k16.G1)          # nothing pending
+
+
+def _hash_style_points(n, seed=0x9E3779B97F4A7C15):
+    """SURVEY 8(d) config 2, second point set: x from a splitmix64 stream, y = (x^3+3)^((p+1)/4), kept if square."""
+    rng = pm.SplitMix64(seed)
+    out = np.zeros((n, 64), dtype=np.uint8)
+    k = 0
+    while k < n:
+        x = (rng.next() | (rng.next() << 64) | (rng.next() << 128) | (rng.next() << 192)) % pm.Q
+        rhs = (x * x * x + 3) % pm.Q
+        y = pow(rhs, (pm.Q + 1) // 4, pm.Q)
+        if y * y % pm.Q != rhs:
+            continue
+        if rng.next() & 1:
+            y = pm.Q - y
+        out[k] = np.frombuffer(pm.g1_aff_bytes((x, y)), dtype=np.uint8)
+        k += 1
+    return out
+
+
+def test_msm_g1_random_curve_points(ctx):
+    # points with no relation to each other (not consecutive multiples of G), uniform and witness-like scalars
+    n = 6000
+    bases = _hash_style_points(n)
+    _check_msm(ctx, 0, bases, np_scalars(301, n, "uniform"))
+    _check_msm(ctx, 0, bases, np_scalars(302, n, "witness"))
+    # and against the affine big-int model on a prefix (independent of the C oracle)
+    m = 40
+    sc = np_scalars(303, m, "full256")
+    _, got = ctx.msm(0, bases[:m], sc)
+    pts = [pm.g1_aff_from_bytes(bytes(bases[i])) for i in range(m)]
+    ks = [int.from_bytes(bytes(sc[i]), "little") for i in range(m)]
+    assert got == pm.g1_aff_bytes(pm.ec_msm(pm.Fq1Ops, pts, ks))
+
+
+@pytest.mark.parametrize("pattern", ["dup_first", "neg_first", "dup_run", "zero_first", "mixed"])
+def test_msm_buckets_with_duplicates_and_negations(ctx, pattern):
+    # every point gets the SAME scalar, so each window has one bucket holding all points in index order: the first add of
+    # the bucket segment is affine + affine (P + P -> doubling, P + (-P) -> infinity, (0,0) rows), later ones mixed adds
+    g = ol.gen_points(0, 0, 8)
+    neg = g.copy()
+    for i in range(8):
+        x, y = pm.g1_aff_from_bytes(bytes(g[i]))
+        neg[i] = np.frombuffer(pm.g1_aff_bytes((x, pm.Q - y)), dtype=np.uint8)
+    zero = np.zeros(64, dtype=np.uint8)
+    rows = {
+        "dup_first": [g[0], g[0], g[1], g[2]],
+        "neg_first": [g[0], neg[0], g[1], neg[1], g[3]],
+        "dup_run": [g[2]] * 7 + [neg[2]] * 3,
+        "zero_first": [zero, g[1], zero, zero, g[1], neg[1], g[1]],
+        "mixed": [g[0], neg[0], g[0], g[0], zero, g[1], g[1], neg[3], g[3], g[3], g[3], g[5]],
+    }[pattern]
+    bases = np.stack(rows * 9)               # > 32 entries: more than one segment per bucket as well
+    n = bases.shape[0]
+    for kind in ("same", "ones"):
+        _check_msm(ctx, 0, bases, np_scalars(77, n, kind))
