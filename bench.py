@@ -36,6 +36,8 @@ LOG2N = 20
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 ALGO_BYTES_PER_POINT = 64 + 32  # G1 MSM = n x (64 B affine point + 32 B scalar)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+MODMUL_PER_PAIR = 10            # SURVEY 8(d) secondary figure: one mixed add (8M + 2S) per (point, window) pair
+MODMUL_PEAK_G = 174.3           # measured on MI355X: radix-2^29 Montgomery multiply, all CUs (profiles/r01/ubench_*.log)
 
 
 def uniform_scalars(n, seed):
@@ -218,6 +220,16 @@ def main():
                 "kernel_ms_isolated": iso_ms / max(iso_launches, 1),
                 "frac_isolated": (n * ALGO_BYTES_PER_POINT) / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
                                  if iso_ms > 0 else None,
+                # the same launch priced in the unit that actually bounds it: 254-bit modular multiplications
+                "alu": {
+                    "unit": "G modmul/s",
+                    "achieved": n * 16 * MODMUL_PER_PAIR / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 if iso_ms > 0 else None,
+                    "peak": MODMUL_PEAK_G,
+                    "frac": n * 16 * MODMUL_PER_PAIR / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 / MODMUL_PEAK_G
+                            if iso_ms > 0 else None,
+                    "basis": "algorithmic 10 modmul x n x 16 windows per launch / kernel_ms_isolated; peak = measured "
+                             "v_mad_u64_u32-bound multiply rate of the radix-2^29 field (no MFMA path exists for 254-bit integers)",
+                },
                 "note": "kernel_ms is the live average inside the timed region, where up to three MSMs share the GPU "
                         "(lanes); kernel_ms_isolated is the same kernel with one MSM at a time. Integer-multiply-issue "
                         "bound in practice; see DESIGN.md (modmul-rate view)",

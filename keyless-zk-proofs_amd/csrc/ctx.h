@@ -50,6 +50,7 @@ struct k16_ctx {
         k16_devbuf  ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
             ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
         // bucket sort still valid in this lane's workspace (same scalars, n, c): see reuse_sort
+        hipEvent_t  sort_done = nullptr; // recorded on `stream` after every bucket sort (cross-lane reuse waits on it)
         const void* sorted_scalars = nullptr;
         uint64_t    sorted_n = 0;
         unsigned    sorted_c = 0;
@@ -81,6 +82,9 @@ struct k16_ctx {
     // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2
     // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)
     bool        reuse_sort = false;
+    // lane whose sort the next MSM reuses (-1: the MSM's own lane).  With another lane the MSM reads that lane's index
+    // lists but runs on its own stream with its own partial / reduction buffers, i.e. concurrently with that lane's MSMs.
+    int         reuse_sort_lane = -1;
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };

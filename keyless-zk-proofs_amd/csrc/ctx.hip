@@ -31,7 +31,8 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     c->device  = device;
     bool lanes_ok = true;
     for (int i = 0; i < k16_ctx::N_LANES; i++)
-        lanes_ok = lanes_ok && hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess;
+        lanes_ok = lanes_ok && hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&c->lanes[i].sort_done, hipEventDisableTiming) == hipSuccess;
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
@@ -75,8 +76,10 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     (void)hipEventDestroy(c->ev_a);
     (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ks_pool) (void)hipEventDestroy(e);
-    for (auto& L : c->lanes)
+    for (auto& L : c->lanes) {
+        if (L.sort_done) (void)hipEventDestroy(L.sort_done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     delete c;
 }
 

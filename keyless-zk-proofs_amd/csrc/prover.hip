@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "ctx.h"
@@ -413,7 +414,14 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         return rc;
     }
     K16_HIP_P(ctx, hipStreamSynchronize(st), p);
-    K16_HIP_P(ctx, hipStreamCreateWithFlags(&p->st2, hipStreamNonBlocking), p);
+    {
+        // the polynomial chain gates the H MSM, the longest item of a proof: its stream gets the highest priority so
+        // that its kernels are not queued behind the witness MSMs that run beside it
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (getenv("K16_NO_STREAM_PRIORITY")) greatest = 0;
+        K16_HIP_P(ctx, hipStreamCreateWithPriority(&p->st2, hipStreamNonBlocking, greatest), p);
+    }
     K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_w, hipEventDisableTiming), p);
     K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming), p);
     *out = p;
@@ -481,6 +489,13 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     K16_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t    st = ctx->stream;
     const uint32_t N  = p->domain_size;
+    static const bool host_trace = getenv("K16_TRACE_HOST") != nullptr;
+    const auto        ht0 = std::chrono::steady_clock::now();
+    auto              ht  = [&](const char* what) {
+        if (host_trace)
+            fprintf(stderr, "[k16 host] %-22s %8.1f us\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count());
+    };
     K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
 
@@ -488,6 +503,7 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     // (groth16.cpp:88-112 vs :116-275); here the chain (HBM-bound) runs on a second stream beside the
     // MSMs (integer-issue-bound) and is joined before the H MSM.
     hipStream_t s2 = p->st2;
+    ht("witness upload issued");
     K16_HIP(ctx, hipEventRecord(p->ev_w, st));
     K16_HIP(ctx, hipStreamWaitEvent(s2, p->ev_w, 0));
     const unsigned gN = (N + 255) / 256;
@@ -508,6 +524,7 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     K16_HIP(ctx, hipGetLastError());
     std::swap(p->d_a, p->d_c);
     K16_HIP(ctx, hipEventRecord(p->ev_h, s2));
+    ht("chain enqueued");
 
     // groth16.cpp:88-112 : the four witness MSMs.  A, B1 and B2 share their scalars (the witness), so the
     // bucket sort of the A MSM is reused for B1 and B2.
@@ -528,8 +545,8 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     if (p->n_vars < (1u << 17)) wc = 0; // small circuits: automatic
     // All five MSMs are enqueued back to back; their host tails (conversion + Horner, ~0.3 ms each, ~1.2 ms for
     // G2) run while later MSMs occupy the GPU.
-    // Lane 0: A, B1, B2 (one shared sort).  Lane 1: C, then H once the polynomial chain is done.  The fold and
-    // weighted-sum stages of one lane leave most CUs idle; the other lane's kernels fill them.
+    // Lane 0: A, B1; lane 2: B2 (A's bucket sort serves all three).  Lane 1: C, then H once the polynomial chain is
+    // done.  The fold and weighted-sum stages of one lane leave most CUs idle; the other lanes' kernels fill them.
     struct LaneReset {
         k16_ctx* c;
         ~LaneReset() { c->cur_lane = 0; }
@@ -547,9 +564,13 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
         ctx->cur_lane   = 0;
         ctx->reuse_sort = true;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
-        ctx->reuse_sort = true;
+        // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
+        ctx->cur_lane        = 2;
+        ctx->reuse_sort      = true;
+        ctx->reuse_sort_lane = 0;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
     }
+    ht("A C B1 B2 enqueued");
     // groth16.cpp:281-283
     ctx->cur_lane = 1;
     K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_h, 0));
@@ -569,7 +590,9 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     memcpy(rs_b, rs.v, 32);
     G1Xyzz d1_rs_neg = pneg(h_mul(d1, rs_b));
 
+    ht("H enqueued + host blinding");
     if ((rc = k16_msm_finish(ctx, &pi_a, nullptr))) return rc;
+    ht("A finished");
     pi_a          = h_madd(pi_a, p->alpha1);
     pi_a          = h_add(pi_a, d1_r);
     G1Xyzz a_s    = h_mul(pi_a, s_std);
@@ -581,7 +604,9 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     if ((rc = k16_msm_finish(ctx, &pi_b, nullptr))) return rc;
     pi_b = h_madd(pi_b, p->beta2);
     pi_b = h_add(pi_b, d2_s);
+    ht("B2 finished");
     if ((rc = k16_msm_finish(ctx, &pih, nullptr))) return rc;
+    ht("H finished");
     K16_HIP(ctx, hipStreamWaitEvent(st, ctx->pend_ev[(ctx->pend_head + k16_ctx::PEND_SLOTS - 1) % k16_ctx::PEND_SLOTS], 0));
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
