@@ -115,19 +115,35 @@ def main():
     scalars = uniform_scalars(n, seed=0xD1B5 + rank)
     d_scalars = ctx.to_device(scalars)
 
+    if os.environ.get("K16_BENCH_C"):           # experiments only: override the automatic window size
+        ctx.set_window_bits(int(os.environ["K16_BENCH_C"]))
+
     import sharding
 
     lane = [0]
 
+    # K16_BENCH_PREPARED=1 (not the headline): the point table converted once to the kernels' row layout, as the prover
+    # does with the zkey's static tables (k16_msm_bases_prepare); the default passes the reference-format table every step
+    prepared = ctx.bases_prepare(k16.G1, d_bases, n) if os.environ.get("K16_BENCH_PREPARED") else None
+
     def enqueue():
         ctx.set_lane(lane[0])            # cycle the MSM lanes (stream + workspace): consecutive MSMs overlap
         lane[0] = (lane[0] + 1) % depth_cell[0]
-        ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
+        if prepared is not None:
+            ctx.msm_enqueue_prepared(k16.G1, prepared, d_scalars, n)
+        else:
+            ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
+
+    pending_x = []   # the previous step's exchange, still in flight
 
     def finish():
         xyzz, _ = ctx.msm_finish(k16.G1)   # waits for THIS MSM only, then conversion + Horner on the host
         if dist is not None:
-            xyzz, _ = sharding.exchange_and_fold(dist, k16.G1, xyzz, device="cuda")
+            # the path's one exchange: start this step's all_gather, complete the previous step's (it ran under the
+            # GPU work enqueued in between); run() drains the last one inside the timed region
+            pending_x.append(sharding.exchange_start(dist, k16.G1, xyzz, device="cuda"))
+            if len(pending_x) > 1:
+                xyzz, _ = sharding.exchange_finish(pending_x.pop(0))
         return xyzz
 
     depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "3")), 3))]
@@ -142,6 +158,8 @@ def main():
             if k + depth - 1 < steps:
                 enqueue()
             res = finish()
+        while pending_x:
+            res, _ = sharding.exchange_finish(pending_x.pop(0))
         return res
 
     if args.warmup:
@@ -205,6 +223,8 @@ def main():
                 "workload": "BN254 G1 Pippenger MSM, 2^%d random scalars/points per GPU, result XYZZ on host"
                             % args.log2n,
                 "points_per_gpu": n,
+                "bases": "prepared once (k16_msm_bases_prepare)" if prepared is not None
+                         else "reference format (Montgomery affine), converted inside every step",
                 "sharding": "independent contiguous shards + RCCL all_gather of 128-B partials" if world > 1
                             else "single GPU",
             },

@@ -19,12 +19,13 @@ def shard_range(n, world, rank):
 
 
 _BUFS = {}
+_SLOTS = 4  # exchanges that may be in flight at once (bench.py overlaps one with the next step's GPU work)
 
 
-def exchange_and_fold(dist, group, partial_xyzz, device=None):
-    """all_gather every rank's partial MSM result and fold them. Returns (xyzz_bytes, affine_bytes).
-    Buffers are cached per (group, world, device): one pinned staging tensor, one send and one receive
-    tensor, so a step costs two small copies and one all_gather_into_tensor."""
+def exchange_start(dist, group, partial_xyzz, device=None):
+    """Begin the exchange of this rank's partial result: copy to the device and issue an asynchronous
+    all_gather_into_tensor.  Returns a handle for exchange_finish.  Buffers are cached per (group, world, device)
+    in a small ring: one pinned staging tensor, one send and one receive tensor per slot."""
     import torch
 
     nbytes = k16.XYZZ_BYTES[group]
@@ -33,14 +34,31 @@ def exchange_and_fold(dist, group, partial_xyzz, device=None):
     key = (group, world, str(device))
     if key not in _BUFS:
         dev = torch.device(device) if device is not None else torch.device("cpu")
-        stage = torch.empty(nbytes, dtype=torch.uint8)
-        if dev.type == "cuda":
-            stage = stage.pin_memory()
-        _BUFS[key] = (stage, torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                      torch.empty(world * nbytes, dtype=torch.uint8, device=dev))
-    stage, send, recv = _BUFS[key]
+        ring = []
+        for _ in range(_SLOTS):
+            stage = torch.empty(nbytes, dtype=torch.uint8)
+            if dev.type == "cuda":
+                stage = stage.pin_memory()
+            ring.append((stage, torch.empty(nbytes, dtype=torch.uint8, device=dev),
+                         torch.empty(world * nbytes, dtype=torch.uint8, device=dev)))
+        _BUFS[key] = [ring, 0]
+    ring, nxt = _BUFS[key]
+    _BUFS[key][1] = (nxt + 1) % _SLOTS
+    stage, send, recv = ring[nxt]
     stage.copy_(torch.frombuffer(bytearray(partial_xyzz), dtype=torch.uint8))
     send.copy_(stage, non_blocking=True)
-    dist.all_gather_into_tensor(recv, send)
+    work = dist.all_gather_into_tensor(recv, send, async_op=True)
+    return (work, recv, group, world, nbytes)
+
+
+def exchange_finish(handle):
+    """Wait for the all_gather and fold the shards' partial results with EC adds. Returns (xyzz_bytes, affine_bytes)."""
+    work, recv, group, world, nbytes = handle
+    work.wait()
     parts = recv.cpu().numpy().reshape(world, nbytes)
     return k16.points_sum(group, np.ascontiguousarray(parts))
+
+
+def exchange_and_fold(dist, group, partial_xyzz, device=None):
+    """all_gather every rank's partial MSM result and fold them. Returns (xyzz_bytes, affine_bytes)."""
+    return exchange_finish(exchange_start(dist, group, partial_xyzz, device))

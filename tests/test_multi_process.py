@@ -69,3 +69,43 @@ def test_shard_range_partition():
                 assert lo == prev and hi >= lo
                 prev = hi
             assert prev == n
+
+
+def _worker_pipelined(rank, world, port, q):
+    """Three MSMs whose exchanges are in flight together (bench.py overlaps step k's exchange with step k+1)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (HERE, os.path.join(ROOT, "keyless-zk-proofs_amd")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+    import oracle_lib as ol
+    import sharding
+    from gpu_common import np_scalars
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 300
+    bases = ol.gen_points(0, 0, n)
+    lo, hi = sharding.shard_range(n, world, rank)
+    handles, wants = [], []
+    for step in range(3):
+        scalars = np_scalars(900 + step, n, "uniform")
+        part, _ = ol.msm(0, bases[lo:hi], scalars[lo:hi])
+        handles.append(sharding.exchange_start(dist, 0, part))
+        wants.append(ol.msm(0, bases, scalars)[1])
+    ok = all(sharding.exchange_finish(h)[1] == w for h, w in zip(handles, wants))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_exchanges_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
