@@ -141,9 +141,12 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
             Fr9            w  = ld_r9(&roots9[j << (S - s0 - t)]);
             Fr9            x1 = tile[(m1 << TL) + tl];
             Fr9            u  = tile[(m0 << TL) + tl];
+            // lazy reduction inside the pass: tile values enter < 2r and grow by 2r per stage (u + t, u - t + 2r with
+            // t < 2r fresh from the multiply), so after K <= 12 stages they are < 26r < 2^259 -- within the 9 x 29-bit
+            // limbs and within the multiply's operand bound (2 * 26 <= 128); one fred9 at the store brings them back
             Fr9            tt = frmul9(w, x1);
-            tile[(m0 << TL) + tl] = fradd9(tt, u);
-            tile[(m1 << TL) + tl] = frsub9(u, tt);
+            tile[(m0 << TL) + tl] = fadd9(u, tt);
+            tile[(m1 << TL) + tl] = fsub9_t<Fr9C, 2>(u, tt);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -152,9 +155,9 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
         const uint32_t mid = e >> TL, tl = e & (T - 1);
         Fr*            dst = &a[base + ((size_t)mid << s0) + tl];
         if (CONV_OUT)
-            st_fr(dst, fr9_to_fr(tile[e]));
+            st_fr(dst, fr9_to_fr(tile[e]));             // multiply by 2^256 / 2^261: any bound <= 64r is fine
         else
-            st_r9(dst, tile[e]);
+            st_r9(dst, fred9_t<Fr9C>(tile[e]));         // < r (1 + 2^-17): fits the 32-byte packed form
     }
 }
 // fft.cpp:226-245 on packed R' data

@@ -186,6 +186,21 @@ int main()
             for (int k = 0; k < 24; k++) { Fr9 m = frmul9(tt, B); Fr mc = fmul(tc, b); Fr9 nu = fradd9(u, m); tt = frsub9(u, m); u = nu; Fr nuc = fadd(uc, mc); tc = fsub(uc, mc); uc = nuc;
                 CHECK(below_kr(u, 3) && below_kr(tt, 3), "fr butterfly invariant"); }
             CHECK(fr9_to_fr(u) == uc && fr9_to_fr(tt) == tc, "fr butterfly chain");
+            // the lazy butterflies of an NTT pass: no reduction for up to 12 stages (bound 2 + 2t), one fred9 at the store
+            {
+                Fr9 lu = A, lt = B; Fr luc = a, ltc = b;
+                for (int k = 1; k <= 12; k++) {
+                    Fr9 m = frmul9(B, lt); Fr mc = fmul(b, ltc);
+                    Fr9 nu = fadd9(lu, m); lt = fsub9_t<Fr9C, 2>(lu, m); lu = nu;
+                    Fr nuc = fadd(luc, mc); ltc = fsub(luc, mc); luc = nuc;
+                    CHECK(normalised(lu) && normalised(lt) && below_kr(lu, 2 + 2 * k) && below_kr(lt, 2 + 2 * k), "lazy butterfly bound");
+                }
+                Fr9 ru = fred9_t<Fr9C>(lu), rt = fred9_t<Fr9C>(lt);
+                CHECK(below_kr(ru, 2) && below_kr(rt, 2) && normalised(ru) && normalised(rt), "fred9 after a lazy pass");
+                CHECK(fr9_to_fr(ru) == luc && fr9_to_fr(rt) == ltc && fr9_to_fr(lu) == luc && fr9_to_fr(lt) == ltc, "lazy butterfly values");
+                uint32_t pw[8]; fr9_store(pw, ru); Fr9 back = fr9_load(pw);
+                CHECK(fr9_to_fr(back) == luc, "lazy pass result survives packing");
+            }
         }
     }
     // ---- Fq2 over Fq9 and the generic XYZZ formulas instantiated on it (G2)
