@@ -31,6 +31,9 @@
 //   * no GPU / HIP failure: the constructor reports ZKEY_FILE_LOAD_ERROR and logs the reason on
 //     stderr; there is no CPU fallback
 //   * the reference's stdout log lines are emitted only when K16_LOG=1
+//   * K16_DEVICES=<comma-separated ordinals> puts one prover per listed device (repeats allowed) behind this one
+//     object; prove() then takes a free one and MAY be called concurrently.  Without it the object
+//     owns a single prover on K16_DEVICE and concurrent callers simply queue.
 #pragma once
 
 class FullProverImpl;

@@ -4,16 +4,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
+#include <new>
+#include <vector>
 
 #include "../../include/k16.h"
 #include "../../include/k16_fullprover.hpp"
 
 namespace {
-
-std::mutex g_ctx_mu;
-k16_ctx*   g_ctx       = nullptr; // one device context per process (one process per GPU)
-int        g_ctx_users = 0;
 
 bool log_on()
 {
@@ -28,28 +27,29 @@ void log_line(const char* level, const char* msg)
     fflush(stdout);
 }
 
-k16_ctx* acquire_ctx()
+// Devices behind one FullProver.  K16_DEVICES="0,1,2,3" puts one resident copy of the key on each listed GPU and lets
+// prove() run on whichever is free; a device may be listed more than once ("0,0,0": three provers sharing one GPU, whose
+// proofs overlap on it).  Default: the single device K16_DEVICE (0).  SURVEY 8(f).3: the pool lives behind the facade, so
+// the Rust side only has to stop serialising prove() calls to use it.
+std::vector<int> device_list()
 {
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (!g_ctx) {
-        int         dev = 0;
-        const char* e   = getenv("K16_DEVICE");
-        if (e) dev = atoi(e);
-        if (k16_ctx_create(dev, &g_ctx) != K16_OK) {
-            g_ctx = nullptr;
-            return nullptr;
+    std::vector<int> devs;
+    if (const char* e = getenv("K16_DEVICES")) {
+        const char* p = e;
+        while (*p) {
+            char* end = nullptr;
+            long  v   = strtol(p, &end, 10);
+            if (end == p) break;
+            devs.push_back((int)v);
+            p = end;
+            while (*p == ',' || *p == ' ') p++;
         }
     }
-    g_ctx_users++;
-    return g_ctx;
-}
-void release_ctx()
-{
-    std::lock_guard<std::mutex> lk(g_ctx_mu);
-    if (g_ctx_users > 0 && --g_ctx_users == 0) {
-        k16_ctx_destroy(g_ctx);
-        g_ctx = nullptr;
+    if (devs.empty()) {
+        const char* e = getenv("K16_DEVICE");
+        devs.push_back(e ? atoi(e) : 0);
     }
+    return devs;
 }
 
 } // namespace
@@ -57,12 +57,42 @@ void release_ctx()
 class FullProverImpl
 {
 public:
-    k16_ctx*    ctx    = nullptr;
-    k16_prover* prover = nullptr;
+    struct Slot {
+        k16_ctx*    ctx    = nullptr;
+        k16_prover* prover = nullptr;
+        bool        busy   = false;
+    };
+    std::vector<Slot>       slots;
+    std::mutex              mu;
+    std::condition_variable cv;
+
     ~FullProverImpl()
     {
-        if (prover) k16_prover_destroy(prover);
-        if (ctx) release_ctx();
+        for (Slot& s : slots) {
+            if (s.prover) k16_prover_destroy(s.prover);
+            if (s.ctx) k16_ctx_destroy(s.ctx);
+        }
+    }
+    // blocks until a prover is free; proofs of concurrent callers run on different slots
+    Slot* acquire()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            for (Slot& s : slots)
+                if (!s.busy) {
+                    s.busy = true;
+                    return &s;
+                }
+            cv.wait(lk);
+        }
+    }
+    void release(Slot* s)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            s->busy = false;
+        }
+        cv.notify_one();
     }
 };
 
@@ -88,23 +118,27 @@ FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullPro
     if (!_zkeyFileName) return;
     FullProverImpl* p = new (std::nothrow) FullProverImpl();
     if (!p) return;
-    p->ctx = acquire_ctx();
-    if (!p->ctx) {
-        fprintf(stderr, "k16 FullProver: no usable MI355X / HIP device; the prover has no CPU fallback\n");
-        delete p;
-        return;
+    for (int dev : device_list()) {
+        FullProverImpl::Slot s;
+        if (k16_ctx_create(dev, &s.ctx) != K16_OK) {
+            fprintf(stderr, "k16 FullProver: no usable MI355X / HIP device %d; the prover has no CPU fallback\n", dev);
+            delete p;
+            return;
+        }
+        int rc = k16_prover_create(s.ctx, _zkeyFileName, &s.prover);
+        if (rc != K16_OK) {
+            // fullprover.cpp:91-100 : invalid_argument -> UNSUPPORTED_ZKEY_CURVE, system_error -> ZKEY_FILE_LOAD_ERROR
+            state = (rc == K16_ERR_CURVE || rc == K16_ERR_FORMAT) ? FullProverState::UNSUPPORTED_ZKEY_CURVE
+                                                                  : FullProverState::ZKEY_FILE_LOAD_ERROR;
+            if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) fprintf(stderr, "k16 FullProver: %s\n", k16_last_error(s.ctx));
+            k16_ctx_destroy(s.ctx);
+            delete p;
+            return;
+        }
+        p->slots.push_back(s);
     }
-    int rc = k16_prover_create(p->ctx, _zkeyFileName, &p->prover);
-    if (rc == K16_OK) {
-        impl  = p;
-        state = FullProverState::OK;
-        return;
-    }
-    // fullprover.cpp:91-100 : invalid_argument -> UNSUPPORTED_ZKEY_CURVE, system_error -> ZKEY_FILE_LOAD_ERROR
-    state = (rc == K16_ERR_CURVE || rc == K16_ERR_FORMAT) ? FullProverState::UNSUPPORTED_ZKEY_CURVE
-                                                          : FullProverState::ZKEY_FILE_LOAD_ERROR;
-    if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) fprintf(stderr, "k16 FullProver: %s\n", k16_last_error(p->ctx));
-    delete p;
+    impl  = p;
+    state = FullProverState::OK;
 }
 
 FullProver::~FullProver()
@@ -119,17 +153,18 @@ ProverResponse FullProver::prove(const char* input) const
     log_line("INFO", "FullProver::prove begin");
     char  json[2048];
     float dev_ms = 0;
+    FullProverImpl::Slot* slot = impl->acquire();
     auto  t0     = std::chrono::high_resolution_clock::now();
-    int   rc     = k16_prover_prove_file(impl->prover, input, nullptr, nullptr, json, sizeof json, &dev_ms);
+    int   rc     = k16_prover_prove_file(slot->prover, input, nullptr, nullptr, json, sizeof json, &dev_ms);
     auto  t1     = std::chrono::high_resolution_clock::now();
+    if (rc < 0 && rc != K16_ERR_CURVE && log_on())
+        fprintf(stderr, "k16 FullProver::prove failed: %s\n", k16_last_error(slot->ctx));
+    impl->release(slot);
     if (rc == K16_ERR_CURVE) {
         log_line("ERROR", "witness file uses a different curve than bn128");
         return ProverResponse(ProverError::WITNESS_GENERATION_INVALID_CURVE);
     }
-    if (rc < 0) {
-        if (log_on()) fprintf(stderr, "k16 FullProver::prove failed: %s\n", k16_last_error(impl->ctx));
-        return ProverResponse(ProverError::INVALID_INPUT);
-    }
+    if (rc < 0) return ProverResponse(ProverError::INVALID_INPUT);
     ProverResponseMetrics m;
     m.prover_time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
     if (log_on()) {

@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include "k16_fullprover.hpp"
 
 struct Peek { // mirrors the field order bindgen sees: { impl, state }
@@ -20,10 +23,27 @@ int main(int argc, char** argv)
     static_assert(sizeof(Peek) == sizeof(FullProver), "FullProver layout");
     memcpy(&pk, &p, sizeof pk);
     printf("state=%d\n", (int)pk.state);
-    for (int i = 0; i < reps; i++) {
-        ProverResponse r = p.prove(argv[2]);
-        printf("type=%d error=%d ms=%d\n", (int)r.type, (int)r.error, r.metrics.prover_time);
-        printf("%s\n", r.raw_json);
+    const int threads = argc > 4 ? atoi(argv[4]) : 1;
+    if (threads <= 1) {
+        for (int i = 0; i < reps; i++) {
+            ProverResponse r = p.prove(argv[2]);
+            printf("type=%d error=%d ms=%d\n", (int)r.type, (int)r.error, r.metrics.prover_time);
+            printf("%s\n", r.raw_json);
+        }
+        return 0;
     }
+    // concurrent callers on ONE FullProver (K16_DEVICES pool behind the facade): each thread proves `reps` times
+    std::mutex               out_mu;
+    std::vector<std::thread> ts;
+    for (int t = 0; t < threads; t++)
+        ts.emplace_back([&]() {
+            for (int i = 0; i < reps; i++) {
+                ProverResponse              r = p.prove(argv[2]);
+                std::lock_guard<std::mutex> lk(out_mu);
+                printf("type=%d error=%d ms=%d\n", (int)r.type, (int)r.error, r.metrics.prover_time);
+                printf("%s\n", r.raw_json);
+            }
+        });
+    for (auto& t : ts) t.join();
     return 0;
 }

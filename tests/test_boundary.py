@@ -26,7 +26,7 @@ def _has_gpu():
 def build_harness(tmp_path):
     exe = str(tmp_path / "fullprover_harness")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), HARNESS_SRC,
-                           "-L", PKG, "-lk16", "-Wl,-rpath," + PKG, "-o", exe])
+                           "-L", PKG, "-lk16", "-Wl,-rpath," + PKG, "-pthread", "-o", exe])
     return exe
 
 
@@ -111,3 +111,29 @@ def test_fullprover_facade_on_gpu(tmp_path, toy_paths):
     other.write_bytes(bytes(w))
     oc = subprocess.run([exe, zkey, str(other)], capture_output=True, text=True, timeout=120)
     assert oc.stdout.splitlines()[1].startswith("type=1 error=3")
+
+
+@pytest.mark.gpu
+def test_fullprover_pool_concurrent_callers(tmp_path, toy_paths):
+    """K16_DEVICES puts several provers behind ONE FullProver; concurrent prove() calls are safe and
+    every proof verifies.  Here three provers share GPU 0 (a multi-GPU node lists 0,1,...,7)."""
+    import json
+    import bn254_pairing as bp
+    zkey, wtns, vk = toy_paths
+    exe = build_harness(tmp_path)
+    env = dict(os.environ, K16_DEVICES="0,0,0")
+    out = subprocess.run([exe, zkey, wtns, "2", "4"], capture_output=True, text=True, timeout=300, env=env)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr
+    proofs = [lines[2 + 2 * k] for k in range(8)]      # 4 threads x 2 proofs
+    for k in range(8):
+        assert lines[1 + 2 * k].startswith("type=0 error=0 ms="), lines
+    assert len(set(proofs)) == 8
+    for js in proofs[:4]:
+        assert json.loads(js)["protocol"] == "groth16"
+        assert bp.verify_json(vk, js, [2])
+    # a pool that names a device that does not exist fails in the constructor, loudly
+    bad = subprocess.run([exe, zkey, wtns], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, K16_DEVICES="0,99"))
+    assert bad.stdout.splitlines()[0] == "state=1"
+    assert "no usable" in bad.stderr
