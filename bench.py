@@ -125,11 +125,15 @@ def main():
     # K16_BENCH_PREPARED=1 (not the headline): the point table converted once to the kernels' row layout, as the prover
     # does with the zkey's static tables (k16_msm_bases_prepare); the default passes the reference-format table every step
     prepared = ctx.bases_prepare(k16.G1, d_bases, n) if os.environ.get("K16_BENCH_PREPARED") else None
+    # K16_BENCH_FIXED_BASE=1 (not the headline either): precomputed window tables for a static point table
+    fixed_tab = ctx.fixed_base_prepare(k16.G1, d_bases, n)[0] if os.environ.get("K16_BENCH_FIXED_BASE") else None
 
     def enqueue():
         ctx.set_lane(lane[0])            # cycle the MSM lanes (stream + workspace): consecutive MSMs overlap
         lane[0] = (lane[0] + 1) % depth_cell[0]
-        if prepared is not None:
+        if fixed_tab is not None:
+            ctx.msm_enqueue_fixed_base(k16.G1, fixed_tab, d_scalars, n)
+        elif prepared is not None:
             ctx.msm_enqueue_prepared(k16.G1, prepared, d_scalars, n)
         else:
             ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
@@ -223,7 +227,8 @@ def main():
                 "workload": "BN254 G1 Pippenger MSM, 2^%d random scalars/points per GPU, result XYZZ on host"
                             % args.log2n,
                 "points_per_gpu": n,
-                "bases": "prepared once (k16_msm_bases_prepare)" if prepared is not None
+                "bases": "fixed-base window tables (k16_msm_fixed_base_prepare)" if fixed_tab is not None
+                         else "prepared once (k16_msm_bases_prepare)" if prepared is not None
                          else "reference format (Montgomery affine), converted inside every step",
                 "sharding": "independent contiguous shards + RCCL all_gather of 128-B partials" if world > 1
                             else "single GPU",

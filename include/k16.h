@@ -95,6 +95,15 @@ int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine);
  * table is passed to k16_msm_enqueue_prepared instead of the zkey-format one. */
 int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out);
 int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_prepared, const void* d_scalars, uint64_t n);
+/* Fixed-base MSM for a static G1 table: W = ceil(257/c) precomputed window tables (row w*n + i =
+ * 2^(c*w) * P_i) let all digit positions share ONE bucket set, so c can be 20 instead of 16 and a 254-bit scalar costs 13
+ * bucket additions instead of 16.  k16_msm_fixed_base_info gives the window size chosen for n (0: not available -- n below
+ * 2^13 or n*W >= 2^25 -- use the ordinary MSM) and the table size in 64-byte rows; k16_msm_fixed_base_prepare fills the
+ * caller's d_table from a zkey-format table (once; ~W*n*(c + 400) field multiplications); k16_msm_enqueue_fixed_base is
+ * k16_msm_enqueue_prepared for such a table (results through k16_msm_finish, same values). */
+int k16_msm_fixed_base_info(uint64_t n, unsigned* c, uint64_t* table_rows);
+int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_table);
+int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d_table, const void* d_scalars, uint64_t n);
 /* A context has K16_MSM_LANES independent MSM lanes (HIP stream + workspace).  The next k16_msm_enqueue* uses the
  * selected lane; MSMs on different lanes may overlap on the GPU (their inputs must already be complete: uploads
  * through k16_h2d are).  k16_msm_finish still returns results in enqueue order.  Default lane 0. */

@@ -325,6 +325,20 @@ K16_HD Fq fq9_to_fq(const Fq9& a)
     return r;
 }
 
+// a^(p-2): the inverse in the same R' domain (Fermat; square-and-multiply over the 254 bits of p - 2).
+// a < 2p, a != 0 mod p; result < 2p.  Used where inversions are rare (building fixed-base window tables).
+K16_HD Fq9 finv9(const Fq9& a)
+{
+    const uint32_t e[8] = {FqParams::P[0] - 2u, FqParams::P[1], FqParams::P[2], FqParams::P[3],
+                           FqParams::P[4],      FqParams::P[5], FqParams::P[6], FqParams::P[7]}; // p - 2 (no borrow)
+    Fq9 r = fq9_one();
+    for (int bit = 253; bit >= 0; bit--) {
+        r = fsqr9(r);
+        if ((e[bit >> 5] >> (bit & 31)) & 1u) r = fmul9(r, a);
+    }
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------------
 // G1 in XYZZ coordinates over Fq9.  Same formulas and the same exceptional-case order as
 // bn254_curve.h (curve.cpp:91-458 of the reference).  Invariant of every stored point:

@@ -69,6 +69,7 @@ struct k16_ctx {
     struct Pend {
         int      group = -1;
         unsigned c = 0, w = 0, nbits = 0, mlog = 0;
+        bool     flat = false; // fixed-base MSM: w = pseudo-windows of the single bucket set
         uint64_t n = 0;
         int      slot = 0;
     };
@@ -78,6 +79,7 @@ struct k16_ctx {
     int        enq_slot = 0;                  // staging slot of the MSM being enqueued
     unsigned   pend_mlog = 0;
     unsigned   pend_nbits = 0;                // written by the kernels' host code for the MSM being enqueued
+    unsigned   pend_wr = 0;                   // (pseudo-)windows whose partial sums were staged
 
     // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2
     // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)

@@ -12,6 +12,8 @@ int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
 int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared);
 int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out, hipStream_t st);
 int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out, hipStream_t st);
+int k16_msm_fixed_tables_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, unsigned c, unsigned W, void* d_table);
+int k16_msm_enqueue_fixed_g1(k16_ctx* ctx, const void* d_table, const void* d_scalars, uint64_t n, unsigned c);
 
 namespace {
 constexpr unsigned MAX_C = 16;
@@ -51,7 +53,99 @@ void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsig
     *out = r;
 }
 
+// Fixed-base MSM (one bucket set for all digit positions): the device leaves, per pseudo-window v of `mag` magnitudes,
+// the same T[v][...] partial sums as an ordinary window; window v stands for the magnitudes v*mag + 1 .. (v+1)*mag, so
+//     result = sum_v val_v + mag * sum_v v * Stot_v        (Stot_v = T[v][nbits+1], the plain sum of the window)
+template <class F>
+void flat_combine_host(const Xyzz<F>* T, unsigned Wr, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
+{
+    Xyzz<F> total = Xyzz<F>::zero(), run = Xyzz<F>::zero(), wsum = Xyzz<F>::zero();
+    for (int v = (int)Wr - 1; v >= 0; v--) {
+        const Xyzz<F>* tw = T + (size_t)v * (nbits + 2);
+        Xyzz<F>        t  = Xyzz<F>::zero();
+        for (int b = (int)nbits - 1; b >= 0; b--) {
+            t = pdbl(t);
+            t = padd(t, tw[b]);
+        }
+        for (unsigned k = 0; k < mlog; k++) t = pdbl(t);
+        t     = padd(t, tw[nbits]);
+        t     = padd(t, tw[nbits + 1]);
+        total = padd(total, t);
+        if (v > 0) {                      // sum_v v * Stot_v by running sums, from the top window down
+            run  = padd(run, tw[nbits + 1]);
+            wsum = padd(wsum, run);
+        }
+    }
+    // mag = 2^(c-1) / Wr = 2^(nbits + mlog)
+    for (unsigned k = 0; k < nbits + mlog; k++) wsum = pdbl(wsum);
+    (void)c;
+    *out = padd(total, wsum);
+}
+
+// window size of the fixed-base tables for n points: the largest supported c <= log2(n) (0: n too small, use the
+// ordinary MSM); W = ceil(257 / c) tables of n rows.  (Cost model: 10 multiplications per (point, digit) pair + ~49 per
+// signed bucket: c = 20 wins from n = 2^20, c = 18 from 2^18, c = 16 from 2^16.)
+unsigned fixed_base_c(uint64_t n)
+{
+    unsigned lg = 0;
+    while ((n >> (lg + 1)) != 0) lg++;
+    static const unsigned cs[] = {20, 18, 16, 14, 12};
+    for (unsigned c : cs)
+        if (lg >= c && (uint64_t)n * ((257 + c - 1) / c) < (1ull << 25)) return c;
+    return 0;
+}
+
 } // namespace
+
+extern "C" int k16_msm_fixed_base_info(uint64_t n, unsigned* c_out, uint64_t* table_rows)
+{
+    const unsigned c = fixed_base_c(n);
+    if (c_out) *c_out = c;
+    if (table_rows) *table_rows = c ? (uint64_t)n * ((257 + c - 1) / c) : 0;
+    return K16_OK;
+}
+
+extern "C" int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_table)
+{
+    if (!ctx || group != K16_G1 || !d_bases || !d_table) return K16_ERR_ARG;
+    const unsigned c = fixed_base_c(n);
+    if (!c) {
+        ctx->err = "fixed-base msm: table too small or too large for this mode (see k16_msm_fixed_base_info)";
+        return K16_ERR_ARG;
+    }
+    return k16_msm_fixed_tables_g1(ctx, d_bases, n, c, (257 + c - 1) / c, d_table);
+}
+
+extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d_table, const void* d_scalars, uint64_t n)
+{
+    if (!ctx || group != K16_G1 || !d_table || !d_scalars) return K16_ERR_ARG;
+    const unsigned c = fixed_base_c(n);
+    if (!c) {
+        ctx->err = "fixed-base msm: unsupported n";
+        return K16_ERR_ARG;
+    }
+    if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
+        ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
+        return K16_ERR_ARG;
+    }
+    const int     idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
+    k16_ctx::Pend pd;
+    pd.group      = group;
+    pd.n          = n;
+    pd.slot       = idx;
+    pd.c          = c;
+    pd.flat       = true;
+    ctx->enq_slot = idx;
+    int rc        = k16_msm_enqueue_fixed_g1(ctx, d_table, d_scalars, n, c);
+    if (rc) return rc;
+    pd.w     = ctx->pend_wr;
+    pd.nbits = ctx->pend_nbits;
+    pd.mlog  = ctx->pend_mlog;
+    K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->lanes[ctx->cur_lane].stream));
+    ctx->pend[idx] = pd;
+    ctx->pend_count++;
+    return K16_OK;
+}
 
 extern "C" int k16_msm_set_lane(k16_ctx* ctx, int lane)
 {
@@ -150,7 +244,10 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
             T[i] = xyzz9_to_canonical(p9);
         }
         G1Xyzz r;
-        horner_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+        if (pd.flat)
+            flat_combine_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+        else
+            horner_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G1Aff a = to_affine(r);

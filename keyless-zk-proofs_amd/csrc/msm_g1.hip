@@ -24,3 +24,52 @@ int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
     }
     return msm_enqueue_t<Eng9>(ctx, rows, d_scalars, n, c);
 }
+
+// ---- fixed-base window tables: row w*n + i = 2^(c*w) * P_i in the packed R' layout.
+// Table 0 is the prepared table itself; table w is c doublings of table w-1, normalised back to affine with one
+// Fermat inversion per point (a load-time cost: ~n * W * (c + 400) multiplications).
+namespace {
+__global__ void __launch_bounds__(128) k_window_table_next(const k16::G1Aff* __restrict__ prev, k16::G1Aff* __restrict__ next,
+                                                           uint64_t n, unsigned c)
+{
+    using namespace k16;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Aff<Fq> w = load_vec(&prev[i]);
+    Aff9    a{fq9_unpack(w.x.v), fq9_unpack(w.y.v)};
+    Aff<Fq> o;
+    for (int k = 0; k < 8; k++) o.x.v[k] = o.y.v[k] = 0; // (0,0) stays (0,0)
+    if (!a.is_zero()) {
+        Xyzz9 p = pdbl_aff9(a);
+#pragma clang loop unroll(disable)
+        for (unsigned k = 1; k < c; k++) p = pdbl9(p);
+        if (!p.is_zero()) {
+            // x = X / ZZ, y = Y / ZZZ with ONE inversion: t = 1 / (ZZ * ZZZ), 1/ZZ = t * ZZZ, 1/ZZZ = t * ZZ
+            Fq9 t = finv9(fmul9(p.zz, p.zzz));
+            Fq9 x = fmul9(p.x, fmul9(t, p.zzz)); // 8 * 2 -> < 2p
+            Fq9 y = fmul9(p.y, fmul9(t, p.zz));  // 4 * 2 -> < 2p
+            fq9_pack(o.x.v, x);
+            fq9_pack(o.y.v, y);
+        }
+    }
+    store_vec(&next[i], o);
+}
+} // namespace
+
+// d_table: W * n rows; rows [0, n) receive the prepared form of d_bases (zkey format), the rest the window tables
+int k16_msm_fixed_tables_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, unsigned c, unsigned W, void* d_table)
+{
+    hipStream_t st = ctx->stream;
+    int         rc = k16_msm_prepare_g1(ctx, d_bases, n, d_table, st);
+    if (rc || n == 0) return rc;
+    k16::G1Aff* t = (k16::G1Aff*)d_table;
+    for (unsigned w = 1; w < W; w++)
+        hipLaunchKernelGGL(k_window_table_next, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, t + (size_t)(w - 1) * n,
+                           t + (size_t)w * n, n, c);
+    K16_HIP(ctx, hipGetLastError());
+    return K16_OK;
+}
+int k16_msm_enqueue_fixed_g1(k16_ctx* ctx, const void* d_table, const void* d_scalars, uint64_t n, unsigned c)
+{
+    return msm_enqueue_t<Eng9>(ctx, (const k16::G1Aff*)d_table, d_scalars, n, c, true);
+}

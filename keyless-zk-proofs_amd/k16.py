@@ -25,7 +25,7 @@ SYMBOLS = [
     "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
-    "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
+    "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
@@ -71,6 +71,9 @@ def load():
     L.k16_msm_finish.argtypes = [vp, vp, vp]
     L.k16_msm_bases_prepare.argtypes = [vp, i32, vp, u64, vp]
     L.k16_msm_enqueue_prepared.argtypes = [vp, i32, vp, vp, u64]
+    L.k16_msm_fixed_base_info.argtypes = [u64, C.POINTER(u32), C.POINTER(u64)]
+    L.k16_msm_fixed_base_prepare.argtypes = [vp, i32, vp, u64, vp]
+    L.k16_msm_enqueue_fixed_base.argtypes = [vp, i32, vp, vp, u64]
     L.k16_msm_set_window_bits.argtypes = [vp, u32]
     L.k16_msm_set_lane.argtypes = [vp, i32]
     L.k16_points_sum.argtypes = [i32, vp, u64, vp, vp]
@@ -196,6 +199,21 @@ class Context:
 
     def msm_enqueue_prepared(self, group, d_prepared, d_scalars, n):
         self._chk(self.L.k16_msm_enqueue_prepared(self.h, group, d_prepared.ptr, d_scalars.ptr, n))
+
+    def fixed_base_prepare(self, group, d_bases, n):
+        """Window tables for a static table (k16_msm_fixed_base_prepare). Returns (DeviceBuffer, c) or (None, 0) when
+        this n has no fixed-base mode."""
+        c, rows = C.c_uint32(0), C.c_uint64(0)
+        self._chk(self.L.k16_msm_fixed_base_info(n, C.byref(c), C.byref(rows)))
+        if c.value == 0:
+            return None, 0
+        out = self.alloc(rows.value * AFF_BYTES[group])
+        self._chk(self.L.k16_msm_fixed_base_prepare(self.h, group, d_bases.ptr, n, out.ptr))
+        self.sync()
+        return out, c.value
+
+    def msm_enqueue_fixed_base(self, group, d_table, d_scalars, n):
+        self._chk(self.L.k16_msm_enqueue_fixed_base(self.h, group, d_table.ptr, d_scalars.ptr, n))
 
     def msm_finish(self, group):
         x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)

@@ -87,6 +87,11 @@ int main()
             Fq  w  = fsub(fmul(fadd(fadd(fadd(a, b), fadd(a, b)), fadd(a, a)), fadd(a, a)), fmul(b, a));
             CHECK(fq9_to_fq(s2) == w && below_kp(s2, 2) && normalised(s2), "a*b + c*d with one reduction");
         }
+        if (it < 300 && !a.is_zero()) {
+            Fq9 inv = finv9(A);
+            CHECK(below_kp(inv, 2) && normalised(inv), "finv9 bound");
+            CHECK(fq9_to_fq(fmul9(inv, A)) == Fq::one(), "finv9: a * a^-1 == 1");
+        }
         CHECK(fq9_is_zero_mod_p<10>(fsub9<8>(A, A)), "x - x == 0 mod p");
         CHECK(fq9_is_zero_mod_p<4>(A) == a.is_zero(), "is_zero");
     }

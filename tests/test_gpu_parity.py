@@ -393,3 +393,65 @@ def test_msm_buckets_with_duplicates_and_negations(ctx, pattern):
     n = bases.shape[0]
     for kind in ("same", "ones"):
         _check_msm(ctx, 0, bases, np_scalars(77, n, kind))
+
+
+# ---------------------------------------------------------------- fixed-base MSM (precomputed window tables)
+def _fixed_base_msm(ctx, d_table, scalars, n):
+    import k16
+    d_s = ctx.to_device(scalars)
+    ctx.msm_enqueue_fixed_base(k16.G1, d_table, d_s, n)
+    xyzz, aff = ctx.msm_finish(k16.G1)
+    d_s.free()
+    return xyzz, aff
+
+
+@pytest.mark.parametrize("n,want_c", [((1 << 13) + 37, 12), ((1 << 15) + 1, 14), (1 << 17, 16), ((1 << 19) + 3, 18)])
+def test_msm_fixed_base_tables_agree_with_oracle(ctx, n, want_c):
+    import k16
+    bases = ol.gen_points(0, 5, n)
+    bases[3] = 0                                  # a (0,0) row stays (0,0) in every window table
+    bases[9] = bases[8]                           # duplicates
+    d_b = ctx.to_device(bases)
+    d_t, c = ctx.fixed_base_prepare(k16.G1, d_b, n)
+    assert c == want_c
+    kinds = ["uniform", "full256", "witness", "ones", "topwindow", "same"] if n < (1 << 18) else ["uniform", "full256"]
+    for kind in kinds:
+        sc = np_scalars(400 + want_c, n, kind)
+        _, want = ol.msm(0, bases, sc, nthreads=8)
+        assert _fixed_base_msm(ctx, d_t, sc, n)[1] == want, kind
+    # the ordinary path on the same inputs, then the fixed-base one again: the two modes share the lane's workspace
+    sc = np_scalars(17, n, "uniform")
+    _, want = ol.msm(0, bases, sc, nthreads=8)
+    assert ctx.msm(0, bases, sc)[1] == want
+    assert _fixed_base_msm(ctx, d_t, sc, n)[1] == want
+    d_t.free()
+    d_b.free()
+
+
+def test_msm_fixed_base_not_available_for_small_tables(ctx):
+    import k16
+    bases = ol.gen_points(0, 0, 1000)
+    d_b = ctx.to_device(bases)
+    d_t, c = ctx.fixed_base_prepare(k16.G1, d_b, 1000)
+    assert d_t is None and c == 0
+    with pytest.raises(k16.K16Error):
+        ctx.msm_enqueue_fixed_base(k16.G1, d_b, d_b, 1000)
+    d_b.free()
+
+
+def test_msm_fixed_base_2p21_closed_form(ctx):
+    """The Keyless H-MSM shape: n = 2^21, c = 20 (13 tables, 1.7 GB): sum_i s_i * (i+1)G against (sum_i s_i (i+1)) * G."""
+    import k16
+    n = 1 << 21
+    d_b = ctx.synth_points(k16.G1, 0, n)
+    d_t, c = ctx.fixed_base_prepare(k16.G1, d_b, n)
+    assert c == 20
+    sc = np_scalars(99, n, "uniform")
+    xyzz, _ = _fixed_base_msm(ctx, d_t, sc, n)
+    vals = sc.view("<u8").reshape(n, 4).astype(object)
+    ints = vals[:, 0] + (vals[:, 1] << 64) + (vals[:, 2] << 128) + (vals[:, 3] << 192)
+    k = int(sum(int(s) * (i + 1) for i, s in enumerate(ints)) % pm.R)
+    want = ol.mul_scalar(0, ol.generator(0), pm.limbs(k))
+    assert ol.pt_eq(0, xyzz, want)
+    d_t.free()
+    d_b.free()
