@@ -455,3 +455,57 @@ def test_msm_fixed_base_2p21_closed_form(ctx):
     assert ol.pt_eq(0, xyzz, want)
     d_t.free()
     d_b.free()
+
+
+# ---------------------------------------------------------------- C-ABI misuse: errors, never crashes or silent results
+def test_c_abi_error_paths(ctx, tmp_path, toy_paths):
+    import ctypes as C
+    import k16
+    L = ctx.L
+    h = ctx.h
+    # finish with nothing in flight
+    out = (C.c_uint8 * 128)()
+    assert L.k16_msm_finish(h, out, None) == -3                                                   # K16_ERR_ARG
+    # more MSMs in flight than staging slots: the 9th enqueue is refused, the first eight still complete correctly
+    n = 64
+    bases = ol.gen_points(0, 0, n)
+    sc = np_scalars(5, n, "uniform")
+    d_b, d_s = ctx.to_device(bases), ctx.to_device(sc)
+    for _ in range(8):
+        ctx.msm_enqueue(k16.G1, d_b, d_s, n)
+    with pytest.raises(k16.K16Error):
+        ctx.msm_enqueue(k16.G1, d_b, d_s, n)
+    _, want = ol.msm(0, bases, sc)
+    for _ in range(8):
+        assert ctx.msm_finish(k16.G1)[1] == want
+    # bad group / lane / window size
+    assert L.k16_msm_enqueue(h, 7, d_b.ptr, d_s.ptr, n) < 0
+    assert L.k16_msm_set_lane(h, 99) < 0
+    assert L.k16_msm_set_window_bits(h, 40) < 0
+    # NTT: size not a power of two, size above the table, domain above the 2-adicity of r
+    a = np.zeros((8, 32), dtype=np.uint8)
+    d_a = ctx.to_device(a)
+    assert L.k16_ntt(h, d_a.ptr, 6, 8, 0) < 0
+    assert L.k16_ntt(h, d_a.ptr, 8, 4, 0) < 0
+    assert L.k16_ntt(h, d_a.ptr, 8, 1 << 29, 0) < 0
+    # prover: missing file, truncated zkey, witness shorter than the circuit, blinding scalar >= r
+    zkey, wtns, _ = toy_paths
+    pp = C.c_void_p()
+    assert L.k16_prover_create(h, str(tmp_path / "missing.zkey").encode(), C.byref(pp)) == -4     # K16_ERR_IO
+    trunc = tmp_path / "trunc.zkey"
+    trunc.write_bytes(open(zkey, "rb").read()[:200])
+    assert L.k16_prover_create(h, str(trunc).encode(), C.byref(pp)) in (-5, -4)                   # K16_ERR_FORMAT
+    pr = k16.Prover(ctx, zkey)
+    nv = pr.info()["n_vars"]
+    short = np.zeros((nv - 1, 32), dtype=np.uint8)
+    with pytest.raises(k16.K16Error):
+        pr.prove_mem(short)
+    w = np.frombuffer(open(wtns, "rb").read()[-nv * 32:], dtype=np.uint8).reshape(nv, 32).copy()
+    big = (pm.R).to_bytes(32, "little")                                                           # r itself: not < r
+    with pytest.raises(k16.K16Error):
+        pr.prove_mem(w, r=big, s=bytes(32))
+    js = pr.prove_mem(w, r=bytes(32), s=bytes(32))                                                 # and the good call still works
+    assert json.loads(js)["protocol"] == "groth16"
+    pr.close()
+    for b in (d_b, d_s, d_a):
+        b.free()
