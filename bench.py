@@ -107,6 +107,9 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     dev = local_rank if world > 1 else 0
+    # fence consecutive bucket accumulations of different lanes (they never overlap anyway): the HIP events around the
+    # kernel then time its execution, not the wait behind the other lane's accumulation (ctx.h, serialize_acc)
+    os.environ.setdefault("K16_SERIALIZE_ACC", "1")
     ctx = k16.Context(dev)  # raises without a GPU / library: there is no CPU fallback
 
     n = 1 << args.log2n
@@ -183,6 +186,9 @@ def main():
     launches, acc_ms = ctx.stats_get("msm_accumulate")
     stage_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
                 for k in ("msm_sort", "msm_accumulate", "msm_fold", "msm_reduce")}
+    # host side of one step (C entry points only): launches, waiting for the GPU, conversion + Horner
+    host_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
+               for k in ("host_enqueue", "host_finish_wait", "host_finish_combine")}
     # the same kernel without a neighbour on the GPU (one MSM at a time), for reference next to the live figure
     ctx.stats_reset()
     saved_depth = depth_cell[0]
@@ -255,11 +261,13 @@ def main():
                     "basis": "algorithmic 10 modmul x n x 16 windows per launch / kernel_ms_isolated; peak = measured "
                              "v_mad_u64_u32-bound multiply rate of the radix-2^29 field (no MFMA path exists for 254-bit integers)",
                 },
-                "note": "kernel_ms is the live average inside the timed region, where up to three MSMs share the GPU "
-                        "(lanes); kernel_ms_isolated is the same kernel with one MSM at a time. Integer-multiply-issue "
-                        "bound in practice; see DESIGN.md (modmul-rate view)",
+                "note": "kernel_ms is the live average inside the timed region (HIP events on the kernel's stream; up to "
+                        "three MSMs share the GPU, so the other lanes' sort / reduction kernels run beside it); "
+                        "kernel_ms_isolated is the same kernel with one MSM at a time. Integer-multiply-issue bound in "
+                        "practice; see DESIGN.md (modmul-rate view)",
             },
             "stage_ms": stage_ms,
+            "host_ms": host_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

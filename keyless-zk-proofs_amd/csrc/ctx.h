@@ -51,6 +51,7 @@ struct k16_ctx {
             ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
         // bucket sort still valid in this lane's workspace (same scalars, n, c): see reuse_sort
         hipEvent_t  sort_done = nullptr; // recorded on `stream` after every bucket sort (cross-lane reuse waits on it)
+        hipEvent_t  acc_done  = nullptr; // recorded after every bucket accumulation (see serialize_acc)
         const void* sorted_scalars = nullptr;
         uint64_t    sorted_n = 0;
         unsigned    sorted_c = 0;
@@ -87,6 +88,12 @@ struct k16_ctx {
     // lane whose sort the next MSM reuses (-1: the MSM's own lane).  With another lane the MSM reads that lane's index
     // lists but runs on its own stream with its own partial / reduction buffers, i.e. concurrently with that lane's MSMs.
     int         reuse_sort_lane = -1;
+    // K16_SERIALIZE_ACC=1 (bench.py sets it): a lane's bucket accumulation waits for the previous lane's.  Two of these
+    // chip-filling kernels never overlap anyway (kernel traces: the second starts when the first ends), so nothing is
+    // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence
+    // the interval also contains the time the launch sits behind the other lane's accumulation.
+    bool        serialize_acc = false;
+    hipEvent_t  last_acc_done = nullptr;
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };

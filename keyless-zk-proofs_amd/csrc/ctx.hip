@@ -32,7 +32,9 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     bool lanes_ok = true;
     for (int i = 0; i < k16_ctx::N_LANES; i++)
         lanes_ok = lanes_ok && hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&c->lanes[i].sort_done, hipEventDisableTiming) == hipSuccess;
+                   hipEventCreateWithFlags(&c->lanes[i].sort_done, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&c->lanes[i].acc_done, hipEventDisableTiming) == hipSuccess;
+    if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
@@ -78,6 +80,7 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     for (hipEvent_t e : c->ks_pool) (void)hipEventDestroy(e);
     for (auto& L : c->lanes) {
         if (L.sort_done) (void)hipEventDestroy(L.sort_done);
+        if (L.acc_done) (void)hipEventDestroy(L.acc_done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     delete c;

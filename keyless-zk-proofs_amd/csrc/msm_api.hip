@@ -2,6 +2,7 @@
 // Kernels live in msm_kernels.inc, instantiated for G1 in msm_g1.hip and for G2 in msm_g2.hip.
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 #include "ctx.h"
 #include "bn254_fq9.h"
@@ -162,8 +163,27 @@ extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
     return K16_OK;
 }
 
+namespace {
+// host-side cost of the MSM entry points (names "host_enqueue", "host_finish_wait", "host_finish_combine" in
+// k16_kernel_stats_get), so that a benchmark can tell a launch-bound host from a busy GPU
+struct HostTimer {
+    k16_ctx*                              c;
+    const char*                           name;
+    std::chrono::steady_clock::time_point t0;
+    HostTimer(k16_ctx* cx, const char* nm) : c(cx), name(nm), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer()
+    {
+        if (!c->stats_on) return;
+        auto& st = c->stats[name];
+        st.launches++;
+        st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+};
+} // namespace
+
 static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, int prepared)
 {
+    HostTimer ht(ctx, "host_enqueue");
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n >= (1ull << 32) / 80) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
         ctx->err = "k16_msm: n too large for one device call; shard it";
@@ -231,7 +251,11 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
         }
         return K16_OK;
     }
-    K16_HIP(ctx, hipEventSynchronize(ctx->pend_ev[pd.slot])); // only this MSM's results; later ones keep running
+    {
+        HostTimer hw(ctx, "host_finish_wait");
+        K16_HIP(ctx, hipEventSynchronize(ctx->pend_ev[pd.slot])); // only this MSM's results; later ones keep running
+    }
+    HostTimer hc(ctx, "host_finish_combine");
     const char*    src = (const char*)ctx->pinned + (size_t)pd.slot * k16_ctx::SLOT_BYTES;
     const unsigned cnt = pd.w * (pd.nbits + 2);
     if (group == K16_G1) {
