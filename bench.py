@@ -107,10 +107,11 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     dev = local_rank if world > 1 else 0
-    # fence consecutive bucket accumulations of different lanes (they never overlap anyway): the HIP events around the
-    # kernel then time its execution, not the wait behind the other lane's accumulation (ctx.h, serialize_acc)
-    os.environ.setdefault("K16_SERIALIZE_ACC", "1")
     ctx = k16.Context(dev)  # raises without a GPU / library: there is no CPU fallback
+    # steps are pipelined over the MSM lanes: throughput tuning (include/k16.h, K16_OPT_PIPELINED_MSM) -- 16 slots per
+    # lane in the weighted bucket sum, and consecutive accumulations fenced so that the HIP events time execution only
+    if int(os.environ.get("K16_BENCH_DEPTH", "3")) > 1:
+        ctx.set_option(k16.OPT_PIPELINED_MSM, 1)
 
     n = 1 << args.log2n
     # this rank's shard of the (world * n)-point MSM: bases (rank*n + i + 1) * G, own scalars

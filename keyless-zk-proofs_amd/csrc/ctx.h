@@ -93,6 +93,9 @@ struct k16_ctx {
     // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence
     // the interval also contains the time the launch sits behind the other lane's accumulation.
     bool        serialize_acc = false;
+    // slots per lane of the first weighted-sum level are capped at 2^wsum_mlog_cap: 8 (3) gives the shortest single MSM;
+    // 16 (4) does 12 % less reduction work with chains twice as long -- +5 % for pipelined MSMs, +4 % latency for one
+    unsigned    wsum_mlog_cap = 3;
     hipEvent_t  last_acc_done = nullptr;
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;

@@ -35,6 +35,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
                    hipEventCreateWithFlags(&c->lanes[i].sort_done, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&c->lanes[i].acc_done, hipEventDisableTiming) == hipSuccess;
     if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
+    if (const char* e = getenv("K16_WSUM_MLOG_CAP")) c->wsum_mlog_cap = (unsigned)atoi(e);
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
@@ -84,6 +85,19 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     delete c;
+}
+
+extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
+{
+    if (!c) return K16_ERR_ARG;
+    switch (option) {
+    case K16_OPT_PIPELINED_MSM:
+        // several MSMs in flight on different lanes, throughput over latency
+        c->serialize_acc = value != 0;
+        c->wsum_mlog_cap = value ? 4 : 3;
+        return K16_OK;
+    default: return K16_ERR_ARG;
+    }
 }
 
 extern "C" const char* k16_last_error(const k16_ctx* c) { return c ? c->err.c_str() : "null context"; }

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("K16_LIB_PATH") or os.path.join(HERE, "libk16.so")  # override: A/B-testing builds
 
 G1, G2 = 0, 1
+OPT_PIPELINED_MSM = 1
 FQ, FR = 0, 1
 OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT = range(7)
 PT_ADD, PT_MADD, PT_DBL = range(3)
@@ -25,7 +26,7 @@ SYMBOLS = [
     "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
-    "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
+    "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
@@ -65,6 +66,7 @@ def load():
     L.k16_kernel_stats_enable.argtypes = [vp, i32]
     L.k16_kernel_stats_reset.argtypes = [vp]
     L.k16_kernel_stats_get.argtypes = [vp, C.c_char_p, C.POINTER(u64), C.POINTER(C.c_double)]
+    L.k16_ctx_set_option.argtypes = [vp, i32, i32]
     L.k16_msm.argtypes = [vp, i32, vp, vp, u64, vp, vp]
     L.k16_msm_host.argtypes = [vp, i32, vp, vp, u64, vp, vp]
     L.k16_msm_enqueue.argtypes = [vp, i32, vp, vp, u64]
@@ -173,6 +175,9 @@ class Context:
         n, ms = C.c_uint64(), C.c_double()
         self._chk(self.L.k16_kernel_stats_get(self.h, name.encode(), C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def set_option(self, option, value):
+        self._chk(self.L.k16_ctx_set_option(self.h, option, value))
 
     def set_lane(self, lane):
         self._chk(self.L.k16_msm_set_lane(self.h, lane))
