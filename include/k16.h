@@ -86,7 +86,10 @@ int k16_kernel_stats_get(k16_ctx* ctx, const char* name, uint64_t* launches, dou
 /* ---- multi-scalar multiplication  (multiexp.cpp:183-245) ----
  * d_bases: n affine points on the device; d_scalars: n x 32 B on the device.
  * Result: XYZZ point (host memory, 128 B for G1 / 256 B for G2), and/or its affine form.
- * Any 256-bit scalar is accepted; (0,0) bases contribute nothing; n == 0 gives infinity. */
+ * Any 256-bit scalar is accepted; (0,0) bases contribute nothing; n == 0 gives infinity.
+ * k16_msm / k16_msm_host take any n that fits the device: above 2^24 points they run contiguous chunks of 2^24 on two
+ * lanes and fold the chunk results (the in-time version of the multi-GPU sharding).  k16_msm_enqueue* is one device
+ * pass and refuses n >= 2^32 / 80. */
 int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, void* h_out_xyzz,
             void* h_out_affine);
 /* same with host buffers (uploads, runs, downloads) */

@@ -297,12 +297,49 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
     return K16_OK;
 }
 
+// One device call handles up to 2^24 points on the fast (LDS partition) sort.  A larger MSM on ONE GPU is the same
+// sharding as across GPUs, done in time: contiguous chunks, alternating lanes so that a chunk's sort
+// overlaps its predecessor's accumulation, and an EC-add fold of the per-chunk results.
+constexpr uint64_t MSM_CHUNK = 1ull << 24;
+
 extern "C" int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n,
                        void* h_out_xyzz, void* h_out_affine)
 {
-    int rc = k16_msm_enqueue(ctx, group, d_bases, d_scalars, n);
-    if (rc) return rc;
-    return k16_msm_finish(ctx, h_out_xyzz, h_out_affine);
+    if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+    if (n <= MSM_CHUNK) {
+        int rc = k16_msm_enqueue(ctx, group, d_bases, d_scalars, n);
+        if (rc) return rc;
+        return k16_msm_finish(ctx, h_out_xyzz, h_out_affine);
+    }
+    if (ctx->pend_count != 0) {
+        ctx->err = "k16_msm: a chunked (n > 2^24) call needs an empty MSM queue";
+        return K16_ERR_ARG;
+    }
+    const size_t   pb       = group == K16_G1 ? sizeof(G1Aff) : sizeof(G2Aff);
+    const size_t   xb       = group == K16_G1 ? sizeof(G1Xyzz) : sizeof(G2Xyzz);
+    const uint64_t chunks   = (n + MSM_CHUNK - 1) / MSM_CHUNK;
+    const int      saved    = ctx->cur_lane;
+    std::vector<unsigned char> parts((size_t)chunks * xb);
+    int      rc = K16_OK;
+    uint64_t enq = 0, fin = 0;
+    auto enqueue_next = [&]() -> int {
+        const uint64_t lo = enq * MSM_CHUNK, cnt = std::min<uint64_t>(MSM_CHUNK, n - lo);
+        ctx->cur_lane = (int)(enq % 2); // two lanes: two chunks in flight
+        enq++;
+        return k16_msm_enqueue(ctx, group, (const char*)d_bases + lo * pb, (const char*)d_scalars + lo * 32, cnt);
+    };
+    rc = enqueue_next();
+    while (!rc && fin < chunks) {
+        if (enq < chunks) rc = enqueue_next();
+        if (!rc) rc = k16_msm_finish(ctx, parts.data() + (size_t)fin * xb, nullptr);
+        fin++;
+    }
+    ctx->cur_lane = saved;
+    if (rc) {
+        while (ctx->pend_count) (void)k16_msm_finish(ctx, nullptr, nullptr); // drain
+        return rc;
+    }
+    return k16_points_sum(group, parts.data(), chunks, h_out_xyzz, h_out_affine);
 }
 
 extern "C" int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const void* h_scalars, uint64_t n,

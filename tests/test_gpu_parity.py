@@ -509,3 +509,21 @@ def test_c_abi_error_paths(ctx, tmp_path, toy_paths):
     pr.close()
     for b in (d_b, d_s, d_a):
         b.free()
+
+
+def test_msm_g1_above_2p24_is_chunked(ctx):
+    """n > 2^24 through k16_msm: chunks of 2^24 on two lanes + EC-add fold (the single-GPU leg of BASELINE config 5).
+    Bases (i+1)G from the device generator, scalars i+1 -> closed form sum (i+1)^2 * G."""
+    import k16
+    n = (1 << 24) + (1 << 20) + 5
+    S = np.zeros((n, 32), dtype=np.uint8)
+    S[:, :4] = np.arange(1, n + 1, dtype=np.uint32).view(np.uint8).reshape(n, 4)
+    d_s = ctx.to_device(S)
+    del S
+    d_b = ctx.synth_points(k16.G1, 0, n)
+    x, _ = ctx.msm_device(k16.G1, d_b, d_s, n)
+    total = n * (n + 1) * (2 * n + 1) // 6
+    want = ol.mul_scalar(0, ol.generator(0), pm.limbs(total % pm.R))
+    assert ol.pt_eq(0, x, want)
+    d_b.free()
+    d_s.free()
