@@ -26,7 +26,7 @@ unsigned choose_c(const k16_ctx* ctx, uint64_t n)
     if (ctx->forced_c >= MIN_C && ctx->forced_c <= MAX_C) return ctx->forced_c;
     unsigned lg = 0;
     while ((n >> (lg + 1)) != 0) lg++;
-    int c = (int)lg - 4;
+    int c = (int)lg - (lg >= 18 ? 3 : 4); // measured on MI355X: 2^16 -> 12/13, 2^18 -> 15, 2^19 -> 15/16, 2^20.. -> 16
     if (c < (int)MIN_C) c = MIN_C;
     if (c > (int)MAX_C) c = MAX_C;
     return (unsigned)c;
