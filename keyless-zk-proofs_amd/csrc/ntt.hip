@@ -130,23 +130,60 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
+    // Lazy reduction inside the pass: tile values enter < 2r and grow by 2r per stage (u + t, u - t + 2r with t < 2r
+    // fresh from the multiply), so after K <= 12 stages they are < 26r < 2^259 -- within the 9 x 29-bit limbs and within
+    // the multiply's operand bound (2 * 26 <= 128); one fred9 at the store brings them back.
     const uint32_t nbf = telem >> 1;
-    for (uint32_t t = 1; t <= K; t++) {
-        const uint32_t half = 1u << (t - 1);
+    uint32_t       t   = 1;
+    if (K & 1) { // odd stage count: one plain radix-2 stage first
+        const uint32_t half = 1u;
         for (uint32_t b = threadIdx.x; b < nbf; b += blockDim.x) {
             const uint32_t tl = b & (T - 1), mm = b >> TL;
             const uint32_t ml = mm & (half - 1), mh = mm >> (t - 1);
             const uint32_t m0 = (mh << t) + ml, m1 = m0 + half;
             const size_t   j  = ((size_t)ml << s0) + lo0 + tl;
-            Fr9            w  = ld_r9(&roots9[j << (S - s0 - t)]);
             Fr9            x1 = tile[(m1 << TL) + tl];
             Fr9            u  = tile[(m0 << TL) + tl];
-            // lazy reduction inside the pass: tile values enter < 2r and grow by 2r per stage (u + t, u - t + 2r with
-            // t < 2r fresh from the multiply), so after K <= 12 stages they are < 26r < 2^259 -- within the 9 x 29-bit
-            // limbs and within the multiply's operand bound (2 * 26 <= 128); one fred9 at the store brings them back
-            Fr9            tt = frmul9(w, x1);
+            Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_r9(&roots9[j << (S - s0 - t)]), x1); // s0 == 0: the twiddle is 1
             tile[(m0 << TL) + tl] = fadd9(u, tt);
             tile[(m1 << TL) + tl] = fsub9_t<Fr9C, 2>(u, tt);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        t = 2;
+    }
+    // two stages (t, t+1) per LDS round trip: a thread owns the 4 elements m0 + {0, h, 2h, 3h} (h = 2^(t-1)); stage t pairs
+    // (m0, m0+h) and (m0+2h, m0+3h) with the SAME twiddle, stage t+1 pairs (m0, m0+2h) and (m0+h, m0+3h) -- exactly the
+    // butterflies and twiddles of the two radix-2 stages (fft.cpp:197-218), with half the LDS traffic and barriers.
+    const uint32_t nq = telem >> 2;
+    for (; t + 1 <= K; t += 2) {
+        const uint32_t h = 1u << (t - 1);
+        for (uint32_t g = threadIdx.x; g < nq; g += blockDim.x) {
+            const uint32_t tl = g & (T - 1), mm = g >> TL;
+            const uint32_t ml = mm & (h - 1), mh = mm >> (t - 1);
+            const uint32_t m0 = (mh << (t + 1)) + ml;
+            const uint32_t i0 = (m0 << TL) + tl, dh = h << TL;
+            const size_t   ja = ((size_t)ml << s0) + lo0 + tl;         // twiddle index of stage t, and of (m0, m0+2h) in t+1
+            const size_t   jb = ((size_t)(ml + h) << s0) + lo0 + tl;   // (m0+h, m0+3h) in stage t+1
+            Fr9            x0 = tile[i0], x1 = tile[i0 + dh], x2 = tile[i0 + 2 * dh], x3 = tile[i0 + 3 * dh];
+            const bool     unit = (s0 == 0 && t == 1); // first two stages of a transform: ja = 0, the twiddles are 1
+            Fr9            p1, p3;
+            if (unit) {
+                p1 = x1;
+                p3 = x3;
+            } else {
+                Fr9 w1 = ld_r9(&roots9[ja << (S - s0 - t)]);
+                p1     = frmul9(w1, x1);
+                p3     = frmul9(w1, x3);
+            }
+            Fr9 a0 = fadd9(x0, p1), a1 = fsub9_t<Fr9C, 2>(x0, p1);
+            Fr9 a2 = fadd9(x2, p3), a3 = fsub9_t<Fr9C, 2>(x2, p3);
+            Fr9 q2 = unit ? a2 : frmul9(ld_r9(&roots9[ja << (S - s0 - t - 1)]), a2);
+            Fr9 q3 = frmul9(ld_r9(&roots9[jb << (S - s0 - t - 1)]), a3);
+            tile[i0]          = fadd9(a0, q2);
+            tile[i0 + 2 * dh] = fsub9_t<Fr9C, 2>(a0, q2);
+            tile[i0 + dh]     = fadd9(a1, q3);
+            tile[i0 + 3 * dh] = fsub9_t<Fr9C, 2>(a1, q3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
