@@ -96,6 +96,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = max(args.gpus, 1)
 
+    if os.environ.get("K16_BENCH_CPUS"):   # experiments: pin the host thread (tools/numa_probe.py)
+        cpus = set()
+        for part in os.environ["K16_BENCH_CPUS"].split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        os.sched_setaffinity(0, cpus)
+
     import torch  # device plumbing + torch.distributed (RCCL); loaded first so one HIP runtime is shared
     import k16
 

@@ -85,6 +85,7 @@ struct k16_ctx {
     // bucket sort of the previous MSM still valid in the workspace (same scalars, n, c): the prover's A / B1 / B2
     // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)
     bool        reuse_sort = false;
+    unsigned    forced_seg = 0; // accumulate segment length override (0: automatic)
     // lane whose sort the next MSM reuses (-1: the MSM's own lane).  With another lane the MSM reads that lane's index
     // lists but runs on its own stream with its own partial / reduction buffers, i.e. concurrently with that lane's MSMs.
     int         reuse_sort_lane = -1;

@@ -549,9 +549,17 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     struct ForcedC {
         k16_ctx* c;
         unsigned saved;
-        ForcedC(k16_ctx* cx, unsigned v) : c(cx), saved(cx->forced_c) { if (!saved && cx_big(cx, v)) c->forced_c = v; }
+        ForcedC(k16_ctx* cx, unsigned v) : c(cx), saved(cx->forced_c)
+        {
+            if (!saved && cx_big(cx, v)) c->forced_c = v;
+            c->forced_seg = 32; // witness scalars: one bucket holds ~45 % of the points, short segments keep it parallel
+        }
         static bool cx_big(k16_ctx*, unsigned) { return true; }
-        ~ForcedC() { c->forced_c = saved; }
+        ~ForcedC()
+        {
+            c->forced_c   = saved;
+            c->forced_seg = 0;
+        }
     };
     G1Xyzz pi_a, pib1, pi_c, pih;
     G2Xyzz pi_b;
