@@ -119,6 +119,11 @@ def main():
     # lane in the weighted bucket sum, and consecutive accumulations fenced so that the HIP events time execution only
     if int(os.environ.get("K16_BENCH_DEPTH", "3")) > 1:
         ctx.set_option(k16.OPT_PIPELINED_MSM, 1)
+    # K16_BENCH_GRAPHS=1: the ~50 launches of an MSM's sort and reduction replayed as two HIP graphs (K16_OPT_GRAPHS).
+    # Off by default: on ROCm 7.2 a hipGraphLaunch of ~25 nodes costs more host time than the launches it replaces
+    # (host_enqueue 0.14 -> 0.45 ms per MSM, 566 -> 470 M points/s)
+    if os.environ.get("K16_BENCH_GRAPHS", "0") != "0":
+        ctx.set_option(k16.OPT_GRAPHS, 1)
 
     n = 1 << args.log2n
     # this rank's shard of the (world * n)-point MSM: bases (rank*n + i + 1) * G, own scalars

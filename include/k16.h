@@ -61,8 +61,11 @@ const char* k16_last_error(const k16_ctx* ctx);
  * (k16_msm_set_lane) and cares about MSMs per second rather than the latency of one: the weighted bucket sum uses 16
  * instead of 8 slots per lane (12 % less work, chains twice as long) and consecutive bucket accumulations of different
  * lanes are fenced one behind the other (they never overlap anyway; the per-kernel HIP-event statistics then time
- * execution only).  Results are identical either way. */
-enum { K16_OPT_PIPELINED_MSM = 1 };
+ * execution only).  Results are identical either way.
+ * K16_OPT_GRAPHS (0/1, default 0): the ~50 launches of an MSM's sort and of its fold + reduction are captured into HIP
+ * graphs (per lane, shape and staging slot) after their second use and replayed with one call each -- for hosts whose
+ * kernel launches are slow.  The per-stage statistics then cover the bucket accumulation only. */
+enum { K16_OPT_PIPELINED_MSM = 1, K16_OPT_GRAPHS = 2 };
 int         k16_ctx_set_option(k16_ctx* ctx, int option, int value);
 int         k16_sync(k16_ctx* ctx);
 /* the HIP stream every kernel of this context is launched on (hipStream_t as void*) */

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 #include <stdint.h>
@@ -50,6 +51,14 @@ struct k16_ctx {
         k16_devbuf  ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
             ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
         // bucket sort still valid in this lane's workspace (same scalars, n, c): see reuse_sort
+        // hipGraph replay of the launch-bound parts of an MSM (see graphs_on): key -> state / executable graph
+        struct GraphEntry {
+            int            state = 0; // 0 unseen, 1 ran eagerly once (workspace sized), 2 captured, -1 capture failed: eager
+            hipGraphExec_t exec  = nullptr;
+        };
+        typedef std::tuple<int, const void*, uint64_t, unsigned, unsigned, unsigned, int> GraphKey;
+        std::map<GraphKey, GraphEntry> graphs;
+        uint64_t                       graphs_gen = 0; // workspace generation the cached graphs were captured for
         hipEvent_t  sort_done = nullptr; // recorded on `stream` after every bucket sort (cross-lane reuse waits on it)
         hipEvent_t  acc_done  = nullptr; // recorded after every bucket accumulation (see serialize_acc)
         const void* sorted_scalars = nullptr;
@@ -86,6 +95,13 @@ struct k16_ctx {
     // MSMs all use the witness as scalars, so the sort is done once (set by the prover, cleared by every sort)
     bool        reuse_sort = false;
     unsigned    forced_seg = 0; // accumulate segment length override (0: automatic)
+    // K16_OPT_GRAPHS: an MSM is ~55 host calls (launches, memsets, events); on a host whose launches are slow (a busy
+    // node: 25 us per call measured, against 2 us) that alone is 1.4 ms per MSM.  With graphs on, the sort and the
+    // fold + reduction + download sequences are captured once per (lane, shape, staging slot) and replayed with one
+    // hipGraphLaunch each; the accumulation stays an ordinary launch (its HIP-event timing keeps working).
+    bool        graphs_on = false;
+    bool        capturing = false; // inside hipStreamBeginCapture: no event-based statistics, no allocation
+    uint64_t    ws_gen = 0;        // bumped by every workspace reallocation: cached graphs hold the old pointers
     // lane whose sort the next MSM reuses (-1: the MSM's own lane).  With another lane the MSM reads that lane's index
     // lists but runs on its own stream with its own partial / reduction buffers, i.e. concurrently with that lane's MSMs.
     int         reuse_sort_lane = -1;
@@ -122,7 +138,8 @@ struct k16_stat_scope {
     k16_ctx*    ctx;
     bool        on;
     hipStream_t st;
-    k16_stat_scope(k16_ctx* c, const char* n, hipStream_t s = nullptr) : ctx(c), on(c->stats_on), st(s ? s : c->stream)
+    k16_stat_scope(k16_ctx* c, const char* n, hipStream_t s = nullptr)
+        : ctx(c), on(c->stats_on && !c->capturing), st(s ? s : c->stream)
     {
         if (on) k16_stats_begin(ctx, n, st);
     }

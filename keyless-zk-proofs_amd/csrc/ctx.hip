@@ -17,6 +17,7 @@ int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes)
     size_t want = bytes + bytes / 8 + 4096;
     K16_HIP(ctx, hipMalloc(&b.p, want));
     b.bytes = want;
+    ctx->ws_gen++;
     return K16_OK;
 }
 
@@ -36,6 +37,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
                    hipEventCreateWithFlags(&c->lanes[i].acc_done, hipEventDisableTiming) == hipSuccess;
     if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
     if (const char* e = getenv("K16_WSUM_MLOG_CAP")) c->wsum_mlog_cap = (unsigned)atoi(e);
+    if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
@@ -80,6 +82,8 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     (void)hipEventDestroy(c->ev_b);
     for (hipEvent_t e : c->ks_pool) (void)hipEventDestroy(e);
     for (auto& L : c->lanes) {
+        for (auto& kv : L.graphs)
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (L.sort_done) (void)hipEventDestroy(L.sort_done);
         if (L.acc_done) (void)hipEventDestroy(L.acc_done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -91,6 +95,9 @@ extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
 {
     if (!c) return K16_ERR_ARG;
     switch (option) {
+    case K16_OPT_GRAPHS:
+        c->graphs_on = value != 0;
+        return K16_OK;
     case K16_OPT_PIPELINED_MSM:
         // several MSMs in flight on different lanes, throughput over latency
         c->serialize_acc = value != 0;

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("K16_LIB_PATH") or os.path.join(HERE, "libk16.so")  # 
 
 G1, G2 = 0, 1
 OPT_PIPELINED_MSM = 1
+OPT_GRAPHS = 2
 FQ, FR = 0, 1
 OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT = range(7)
 PT_ADD, PT_MADD, PT_DBL = range(3)
