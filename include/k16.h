@@ -82,7 +82,7 @@ int k16_timer_start(k16_ctx* ctx);
 int k16_timer_stop(k16_ctx* ctx, float* elapsed_ms); /* synchronises */
 /* per-kernel statistics: when enabled, the named hot kernels are bracketed by HIP events.
  * name: "msm_accumulate", "msm_sort", "msm_reduce", "ntt".  total_ms / launches since reset. */
-int k16_kernel_stats_enable(k16_ctx* ctx, int on);
+int k16_kernel_stats_enable(k16_ctx* ctx, int on); /* 0 off, 1 all stages, 2 only "msm_accumulate" (+ the host_* timers) */
 int k16_kernel_stats_reset(k16_ctx* ctx);
 int k16_kernel_stats_get(k16_ctx* ctx, const char* name, uint64_t* launches, double* total_ms);
 

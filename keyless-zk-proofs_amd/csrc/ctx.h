@@ -36,7 +36,7 @@ struct k16_ctx {
     std::vector<hipEvent_t> ks_pool;
     std::vector<std::pair<std::string, size_t>> ks_pending; // (name, index of the start event in ks_pool)
     size_t      ks_used = 0;
-    bool        stats_on = false;
+    int         stats_on = 0; // 0 off, 1 every named stage, 2 only "msm_accumulate" (two HIP events per MSM instead of eight)
     std::map<std::string, k16_kstat> stats;
     std::string err;
     unsigned    forced_c = 0;
@@ -139,7 +139,7 @@ struct k16_stat_scope {
     bool        on;
     hipStream_t st;
     k16_stat_scope(k16_ctx* c, const char* n, hipStream_t s = nullptr)
-        : ctx(c), on(c->stats_on && !c->capturing), st(s ? s : c->stream)
+        : ctx(c), on((c->stats_on == 1 || (c->stats_on == 2 && n[4] == 'a')) && !c->capturing), st(s ? s : c->stream)
     {
         if (on) k16_stats_begin(ctx, n, st);
     }

@@ -197,7 +197,7 @@ extern "C" int k16_kernel_stats_enable(k16_ctx* c, int on)
 {
     if (!c) return K16_ERR_ARG;
     int rc = k16_stats_resolve(c);
-    c->stats_on = on != 0;
+    c->stats_on = on < 0 ? 0 : (on > 2 ? 1 : on);
     return rc;
 }
 extern "C" int k16_kernel_stats_reset(k16_ctx* c)

@@ -167,7 +167,7 @@ class Context:
         return ms.value
 
     def stats_enable(self, on=True):
-        self._chk(self.L.k16_kernel_stats_enable(self.h, 1 if on else 0))
+        self._chk(self.L.k16_kernel_stats_enable(self.h, int(on)))
 
     def stats_reset(self):
         self._chk(self.L.k16_kernel_stats_reset(self.h))
