@@ -168,16 +168,48 @@ def main():
 
     depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "3")), 3))]
 
+    import threading
+
     def run(steps):
-        """steps complete MSMs, `depth` of them in flight: MSM k+depth-1 is enqueued before MSM k is finished."""
+        """steps complete MSMs, up to `depth` of them in flight.  The launches of MSM k+depth-1 are issued by a second host
+        thread while this one waits for MSM k and combines its partial sums (the C entry points allow one enqueuing and
+        one finishing thread): on a host whose HIP calls are slow the ~40 launches of an MSM then no longer sit between two
+        waits.  K16_BENCH_THREADED=0: everything from this thread."""
         depth = depth_cell[0]
         res = None
-        for k in range(min(depth - 1, steps)):
-            enqueue()
-        for k in range(steps):
-            if k + depth - 1 < steps:
+        # (not with torch.distributed: its Python-side calls and the producer then fight over the interpreter lock)
+        if depth == 1 or os.environ.get("K16_BENCH_THREADED", "1" if dist is None else "0") == "0":
+            for k in range(min(depth - 1, steps)):
                 enqueue()
-            res = finish()
+            for k in range(steps):
+                if k + depth - 1 < steps:
+                    enqueue()
+                res = finish()
+        else:
+            room, ready, failed = threading.Semaphore(depth), threading.Semaphore(0), []
+
+            def producer():
+                try:
+                    for _ in range(steps):
+                        room.acquire()
+                        enqueue()
+                        ready.release()
+                except BaseException as e:   # surface in the main thread instead of deadlocking it
+                    failed.append(e)
+                    for _ in range(steps):
+                        ready.release()
+
+            th = threading.Thread(target=producer)
+            th.start()
+            for k in range(steps):
+                ready.acquire()
+                if failed:
+                    break
+                res = finish()
+                room.release()
+            th.join()
+            if failed:
+                raise failed[0]
         while pending_x:
             res, _ = sharding.exchange_finish(pending_x.pop(0))
         return res

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -83,6 +84,9 @@ struct k16_ctx {
         uint64_t n = 0;
         int      slot = 0;
     };
+    // One thread may enqueue while another finishes (bench.py does: launches on a slow host then overlap the wait for the
+    // GPU): the ring bookkeeping and the host timers are guarded; everything else an enqueue touches is its own.
+    std::mutex ring_mu;
     Pend       pend[PEND_SLOTS];
     int        pend_head = 0, pend_count = 0; // ring: oldest at pend_head
     hipEvent_t pend_ev[PEND_SLOTS] = {};

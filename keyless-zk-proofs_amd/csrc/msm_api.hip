@@ -125,11 +125,16 @@ extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d
         ctx->err = "fixed-base msm: unsupported n";
         return K16_ERR_ARG;
     }
-    if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
-        ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
-        return K16_ERR_ARG;
+    K16_HIP(ctx, hipSetDevice(ctx->device));
+    int idx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
+            ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
+            return K16_ERR_ARG;
+        }
+        idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
     }
-    const int     idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
     k16_ctx::Pend pd;
     pd.group      = group;
     pd.n          = n;
@@ -143,8 +148,11 @@ extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d
     pd.nbits = ctx->pend_nbits;
     pd.mlog  = ctx->pend_mlog;
     K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->lanes[ctx->cur_lane].stream));
-    ctx->pend[idx] = pd;
-    ctx->pend_count++;
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        ctx->pend[idx] = pd;
+        ctx->pend_count++;
+    }
     return K16_OK;
 }
 
@@ -174,6 +182,7 @@ struct HostTimer {
     ~HostTimer()
     {
         if (!c->stats_on) return;
+        std::lock_guard<std::mutex> lk(c->ring_mu);
         auto& st = c->stats[name];
         st.launches++;
         st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -184,16 +193,21 @@ struct HostTimer {
 static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, int prepared)
 {
     HostTimer ht(ctx, "host_enqueue");
+    K16_HIP(ctx, hipSetDevice(ctx->device)); // the calling thread may be new (bench.py enqueues from a second thread)
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n >= (1ull << 32) / 80) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
         ctx->err = "k16_msm: n too large for one device call; shard it";
         return K16_ERR_ARG;
     }
-    if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
-        ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
-        return K16_ERR_ARG;
+    int idx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
+            ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
+            return K16_ERR_ARG;
+        }
+        idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS; // = (number enqueued so far) mod slots
     }
-    const int     idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
     k16_ctx::Pend pd;
     pd.group = group;
     pd.n     = n;
@@ -211,8 +225,11 @@ static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const v
         pd.mlog  = ctx->pend_mlog;
         K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->lanes[ctx->cur_lane].stream));
     }
-    ctx->pend[idx] = pd;
-    ctx->pend_count++;
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        ctx->pend[idx] = pd;
+        ctx->pend_count++;
+    }
     return K16_OK;
 }
 
@@ -234,10 +251,15 @@ extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_base
 
 extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
 {
-    if (!ctx || ctx->pend_count == 0) return K16_ERR_ARG;
-    const k16_ctx::Pend pd = ctx->pend[ctx->pend_head];
-    ctx->pend_head         = (ctx->pend_head + 1) % k16_ctx::PEND_SLOTS;
-    ctx->pend_count--;
+    if (!ctx) return K16_ERR_ARG;
+    k16_ctx::Pend pd;
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        if (ctx->pend_count == 0) return K16_ERR_ARG;
+        pd             = ctx->pend[ctx->pend_head];
+        ctx->pend_head = (ctx->pend_head + 1) % k16_ctx::PEND_SLOTS;
+        ctx->pend_count--;
+    }
     const int group = pd.group;
     if (pd.n == 0) {
         if (group == K16_G1) {

@@ -37,25 +37,38 @@ def exchange_start(dist, group, partial_xyzz, device=None):
         ring = []
         for _ in range(_SLOTS):
             stage = torch.empty(nbytes, dtype=torch.uint8)
+            back = torch.empty(world * nbytes, dtype=torch.uint8)
             if dev.type == "cuda":
                 stage = stage.pin_memory()
+                back = back.pin_memory()
             ring.append((stage, torch.empty(nbytes, dtype=torch.uint8, device=dev),
-                         torch.empty(world * nbytes, dtype=torch.uint8, device=dev)))
+                         torch.empty(world * nbytes, dtype=torch.uint8, device=dev), back))
         _BUFS[key] = [ring, 0]
     ring, nxt = _BUFS[key]
     _BUFS[key][1] = (nxt + 1) % _SLOTS
-    stage, send, recv = ring[nxt]
+    stage, send, recv, back = ring[nxt]
     stage.copy_(torch.frombuffer(bytearray(partial_xyzz), dtype=torch.uint8))
     send.copy_(stage, non_blocking=True)
     work = dist.all_gather_into_tensor(recv, send, async_op=True)
-    return (work, recv, group, world, nbytes)
+    done = None
+    if recv.is_cuda:
+        # the download is queued right behind the collective (stream-ordered): exchange_finish only waits for an event
+        work.wait()                       # the current stream waits for the collective; the host does not
+        back.copy_(recv, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+    return (work, recv, back, done, group, world, nbytes)
 
 
 def exchange_finish(handle):
     """Wait for the all_gather and fold the shards' partial results with EC adds. Returns (xyzz_bytes, affine_bytes)."""
-    work, recv, group, world, nbytes = handle
-    work.wait()
-    parts = recv.cpu().numpy().reshape(world, nbytes)
+    work, recv, back, done, group, world, nbytes = handle
+    if done is not None:
+        done.synchronize()
+        parts = back.numpy().reshape(world, nbytes)
+    else:
+        work.wait()
+        parts = recv.numpy().reshape(world, nbytes)
     return k16.points_sum(group, np.ascontiguousarray(parts))
 
 
