@@ -499,20 +499,20 @@ K16_HD Fq2n fadd(const Fq2n& x, const Fq2n& y) { return Fq2n{fred9(fadd9(x.a, y.
 K16_HD Fq2n fsub(const Fq2n& x, const Fq2n& y) { return Fq2n{fred9(fsub9<4>(x.a, y.a)), fred9(fsub9<4>(x.b, y.b))}; } // 4p offset: slack for the 2p+eps invariant
 K16_HD Fq2n fdbl(const Fq2n& x) { return Fq2n{fred9(fdbl9(x.a)), fred9(fdbl9(x.b))}; }
 K16_HD Fq2n fneg(const Fq2n& x) { return fsub(Fq2n::zero(), x); }
-// f2field.cpp:122-142 (Karatsuba, non-residue -1): sums < 4p each, 4*4 = 16 <= 128
+// f2field.cpp:122-142 computes (a + bu)(c + du) = (ac - bd) + (ad + bc)u with Karatsuba's three products.  Here each
+// component is ONE Montgomery reduction of two products (fmul9_sum2): 4 x 81 product terms + 2 x 81 reduction terms, the
+// same 486 multiply-adds as 3 full multiplications, but none of Karatsuba's five additions / subtractions and no partial
+// reduction afterwards: bounds 2*2 + 4*2 = 12 and 2*2 + 2*2 = 8 of the 128 allowed, results < 2p.
 K16_HD Fq2n fmul(const Fq2n& x, const Fq2n& y)
 {
-    Fq9 aa = fmul9(x.a, y.a);
-    Fq9 bb = fmul9(x.b, y.b);
-    Fq9 s  = fmul9(fadd9(x.a, x.b), fadd9(y.a, y.b));
-    return Fq2n{fred9(fsub9<4>(aa, bb)), fred9(fsub9<4>(fsub9<4>(s, aa), bb))}; // < 6p and < 10p before fred9 (valid to 16p)
+    const Fq9 nb = fsub9<4>(fq9_zero(), x.b); // 4p - b  (b < 2p + eps)
+    return Fq2n{fmul9_sum2(x.a, y.a, nb, y.b), fmul9_sum2(x.a, y.b, x.b, y.a)};
 }
 // f2field.cpp:144-158 (complex squaring)
 K16_HD Fq2n fsqr(const Fq2n& x)
 {
-    Fq9 ab = fmul9(x.a, x.b);
     Fq9 ra = fmul9(fadd9(x.a, x.b), fsub9<4>(x.a, x.b)); // 4 * 6 = 24
-    return Fq2n{ra, fred9(fdbl9(ab))};
+    return Fq2n{ra, fmul9(fdbl9(x.a), x.b)};              // 2ab as (2a) * b: 4 * 2 = 8, no reduction afterwards
 }
 
 K16_HD Fq2n fq2n_from_canonical(const Fq2& x) { return Fq2n{fq9_from_fq(x.a), fq9_from_fq(x.b)}; }
