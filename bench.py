@@ -85,8 +85,8 @@ def cpu_baseline(n_sample, scalars):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)   # 0.2 s of GPU time: long enough to amortise pipeline fill / drain
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=LOG2N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
