@@ -4,8 +4,8 @@
 Workload (BASELINE.json configs[1]): BN254 G1 Pippenger MSM, 2^20 points, uniform random scalars in
 [0, r), bases (i+1)*G -- all resident in HBM before the timed region.  One "step" = one complete MSM
 (digits -> bucket sort -> bucket accumulation -> weighted bucket reduction -> Horner combine ->
-XYZZ result on the host).  Steps are software-pipelined three deep over the context's MSM lanes (stream +
-workspace each): the kernels of steps k+1, k+2 are enqueued before step k is finished, so the latency-bound
+XYZZ result on the host).  Steps are software-pipelined four deep over the context's MSM lanes (stream +
+workspace each): the kernels of steps k+1 .. k+3 are enqueued before step k is finished, so the latency-bound
 fold / reduction stages of one MSM overlap the next one's sort and accumulation and the 0.25 ms host tail is
 hidden; the timed region still contains exactly K complete MSMs, each fully reduced to one point.
 
@@ -117,7 +117,7 @@ def main():
     ctx = k16.Context(dev)  # raises without a GPU / library: there is no CPU fallback
     # steps are pipelined over the MSM lanes: throughput tuning (include/k16.h, K16_OPT_PIPELINED_MSM) -- 16 slots per
     # lane in the weighted bucket sum, and consecutive accumulations fenced so that the HIP events time execution only
-    if int(os.environ.get("K16_BENCH_DEPTH", "3")) > 1:
+    if int(os.environ.get("K16_BENCH_DEPTH", "4")) > 1:
         ctx.set_option(k16.OPT_PIPELINED_MSM, 1)
     # K16_BENCH_GRAPHS=1: the ~50 launches of an MSM's sort and reduction replayed as two HIP graphs (K16_OPT_GRAPHS).
     # Off by default: on ROCm 7.2 a hipGraphLaunch of ~25 nodes costs more host time than the launches it replaces
@@ -166,7 +166,7 @@ def main():
                 xyzz, _ = sharding.exchange_finish(pending_x.pop(0))
         return xyzz
 
-    depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "3")), 3))]
+    depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "4")), 4))]
 
     import threading
 

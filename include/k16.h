@@ -120,7 +120,7 @@ int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d_table, con
 /* A context has K16_MSM_LANES independent MSM lanes (HIP stream + workspace).  The next k16_msm_enqueue* uses the
  * selected lane; MSMs on different lanes may overlap on the GPU (their inputs must already be complete: uploads
  * through k16_h2d are).  k16_msm_finish still returns results in enqueue order.  Default lane 0. */
-#define K16_MSM_LANES 3
+#define K16_MSM_LANES 4
 int k16_msm_set_lane(k16_ctx* ctx, int lane);
 /* override the window size chosen for the next MSMs (0 = automatic) */
 int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c);

@@ -46,7 +46,7 @@ struct k16_ctx {
     // MSM lanes: independent (stream, workspace) pairs.  MSMs enqueued on different lanes may overlap on the
     // GPU -- the fold / weighted-sum stages are latency-bound chains on few lanes and leave most CUs idle, so a
     // second MSM's sort or accumulation fills them.  Lane 0's stream is also ctx->stream.
-    static constexpr int N_LANES = 3;
+    static constexpr int N_LANES = 4;
     struct Lane {
         hipStream_t stream = nullptr;
         k16_devbuf  ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
@@ -121,6 +121,12 @@ struct k16_ctx {
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };
+
+// Lane streams are created on first use: ROCm multiplexes a process's streams onto 4 hardware queues by default
+// (GPU_MAX_HW_QUEUES), so a stream that is never used must not take one from those that are -- the prover runs lanes
+// 0-2 plus its chain stream, the MSM benchmark lanes 0-3 (measured: with an idle fifth stream a proof took 8.7 instead
+// of 7.7 ms).
+hipStream_t k16_lane_stream(k16_ctx* ctx, int lane);
 
 #define K16_HIP(ctx, call)                                                                         \
     do {                                                                                           \

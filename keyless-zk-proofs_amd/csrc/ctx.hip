@@ -32,7 +32,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     c->device  = device;
     bool lanes_ok = true;
     for (int i = 0; i < k16_ctx::N_LANES; i++)
-        lanes_ok = lanes_ok && hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess &&
+        lanes_ok = lanes_ok && (i > 0 || hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess) &&
                    hipEventCreateWithFlags(&c->lanes[i].sort_done, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&c->lanes[i].acc_done, hipEventDisableTiming) == hipSuccess;
     if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
@@ -86,9 +86,22 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (L.sort_done) (void)hipEventDestroy(L.sort_done);
         if (L.acc_done) (void)hipEventDestroy(L.acc_done);
-        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.stream && (&L == &c->lanes[0] || L.stream != c->lanes[0].stream)) (void)hipStreamDestroy(L.stream);
     }
     delete c;
+}
+
+hipStream_t k16_lane_stream(k16_ctx* ctx, int lane)
+{
+    k16_ctx::Lane& L = ctx->lanes[lane];
+    if (!L.stream) {
+        (void)hipSetDevice(ctx->device);
+        if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) {
+            ctx->err = "hipStreamCreate (MSM lane)";
+            L.stream = ctx->stream; // degrade to lane 0's stream rather than fail: results are the same
+        }
+    }
+    return L.stream;
 }
 
 extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)

@@ -147,7 +147,7 @@ extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d
     pd.w     = ctx->pend_wr;
     pd.nbits = ctx->pend_nbits;
     pd.mlog  = ctx->pend_mlog;
-    K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->lanes[ctx->cur_lane].stream));
+    K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], k16_lane_stream(ctx, ctx->cur_lane)));
     {
         std::lock_guard<std::mutex> lk(ctx->ring_mu);
         ctx->pend[idx] = pd;
@@ -223,7 +223,7 @@ static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const v
         if (rc) return rc;
         pd.nbits = ctx->pend_nbits;
         pd.mlog  = ctx->pend_mlog;
-        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], ctx->lanes[ctx->cur_lane].stream));
+        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], k16_lane_stream(ctx, ctx->cur_lane)));
     }
     {
         std::lock_guard<std::mutex> lk(ctx->ring_mu);

@@ -19,7 +19,7 @@ int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
         k16_ctx::Lane& L = ctx->lanes[ctx->cur_lane];
         int rc = k16_ws_reserve(ctx, L.ws_conv, (size_t)n * sizeof(k16::G1Aff));
         if (rc) return rc;
-        if ((rc = k16_msm_prepare_g1(ctx, d_bases, n, L.ws_conv.p, L.stream))) return rc;
+        if ((rc = k16_msm_prepare_g1(ctx, d_bases, n, L.ws_conv.p, k16_lane_stream(ctx, ctx->cur_lane)))) return rc;
         rows = (const k16::G1Aff*)L.ws_conv.p;
     }
     return msm_enqueue_t<Eng9>(ctx, rows, d_scalars, n, c);

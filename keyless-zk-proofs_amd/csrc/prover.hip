@@ -574,7 +574,7 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
         k16_ctx* c;
         ~LaneReset() { c->cur_lane = 0; }
     } lane_reset{ctx};
-    hipStream_t s1 = ctx->lanes[1].stream;
+    hipStream_t s1 = k16_lane_stream(ctx, 1);
     K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_w, 0)); // witness upload (lane 0's stream)
     {
         ForcedC fc(ctx, wc);
