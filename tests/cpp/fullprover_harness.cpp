@@ -3,6 +3,7 @@
 // Output (one line each): state=<int> type=<int> error=<int> ms=<int> then the JSON (if any).
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -25,16 +26,20 @@ int main(int argc, char** argv)
     printf("state=%d\n", (int)pk.state);
     const int threads = argc > 4 ? atoi(argv[4]) : 1;
     if (threads <= 1) {
+        const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < reps; i++) {
             ProverResponse r = p.prove(argv[2]);
             printf("type=%d error=%d ms=%d\n", (int)r.type, (int)r.error, r.metrics.prover_time);
             printf("%s\n", r.raw_json);
         }
+        printf("elapsed_ms=%.3f proofs=%d\n",
+               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), reps);
         return 0;
     }
     // concurrent callers on ONE FullProver (K16_DEVICES pool behind the facade): each thread proves `reps` times
     std::mutex               out_mu;
     std::vector<std::thread> ts;
+    const auto               t_begin = std::chrono::steady_clock::now();
     for (int t = 0; t < threads; t++)
         ts.emplace_back([&]() {
             for (int i = 0; i < reps; i++) {
@@ -45,5 +50,7 @@ int main(int argc, char** argv)
             }
         });
     for (auto& t : ts) t.join();
+    printf("elapsed_ms=%.3f proofs=%d\n",
+           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(), threads * reps);
     return 0;
 }

@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the circuit (1.0 = Keyless shape)")
     ap.add_argument("--proofs", type=int, default=10)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--facade", type=int, default=0,
+                    help="also drive the C++ FullProver facade (tests/cpp/fullprover_harness.cpp) with this many threads over "
+                         "a pool of as many provers on GPU 0 (K16_DEVICES=0,0,..)")
     ap.add_argument("--concurrent", type=int, default=1, help="throughput mode: this many provers (own context, streams) share the GPU")
     args = ap.parse_args()
     n_vars = max(int(1343588 * args.scale), 8)
@@ -144,6 +147,25 @@ def main():
         print(json.dumps({"metric": "Groth16 proofs/s, throughput mode (%d provers sharing 1 MI355X)" % args.concurrent,
                           "value": args.proofs * len(provers) / total, "p50_ms": float(np.median(allv)),
                           "p99_ms": float(np.percentile(allv, 99))}), flush=True)
+    if args.facade:
+        import subprocess
+        wpath = "/tmp/k16_synth.wtns"
+        sec1 = struct.pack("<I", 32) + le32(R) + struct.pack("<I", n_vars)
+        with open(wpath, "wb") as f:
+            f.write(b"wtns" + struct.pack("<II", 2, 2) + section(1, sec1) + section(2, wits[0].tobytes()))
+        exe = "/tmp/k16_fullprover_harness"
+        pkg = os.path.join(ROOT, "keyless-zk-proofs_amd")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "fullprover_harness.cpp"), "-L", pkg, "-lk16",
+                               "-Wl,-rpath," + pkg, "-pthread", "-o", exe])
+        env = dict(os.environ, K16_DEVICES=",".join(["0"] * args.facade))
+        out = subprocess.run([exe, zpath, wpath, str(args.proofs), str(args.facade)], capture_output=True, text=True, env=env)
+        last = [l for l in out.stdout.splitlines() if l.startswith("elapsed_ms=")]
+        ok = sum(1 for l in out.stdout.splitlines() if l.startswith("type=0 error=0"))
+        ms = float(last[0].split()[0].split("=")[1]) if last else float("nan")
+        print(json.dumps({"metric": "Groth16 proofs/s through the C++ FullProver facade (%d threads, pool of %d provers on one MI355X)"
+                                    % (args.facade, args.facade),
+                          "value": ok / (ms * 1e-3), "proofs_ok": ok, "elapsed_ms": ms}), flush=True)
     if args.check:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as ol
