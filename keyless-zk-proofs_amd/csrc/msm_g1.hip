@@ -15,14 +15,22 @@ int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_ou
 int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars, uint64_t n, unsigned c, int prepared)
 {
     const k16::G1Aff* rows = (const k16::G1Aff*)d_bases;
+    const void*       conv_in = nullptr;
     if (!prepared) {
         k16_ctx::Lane& L = ctx->lanes[ctx->cur_lane];
         int rc = k16_ws_reserve(ctx, L.ws_conv, (size_t)n * sizeof(k16::G1Aff));
         if (rc) return rc;
-        if ((rc = k16_msm_prepare_g1(ctx, d_bases, n, L.ws_conv.p, k16_lane_stream(ctx, ctx->cur_lane)))) return rc;
         rows = (const k16::G1Aff*)L.ws_conv.p;
+        // the conversion rides in the sort's counting pass when there is one (LDS partition sort, no reused sort, no
+        // captured graphs -- a graph would pin this call's table pointer); otherwise it is a kernel of its own
+        const bool fuse = n <= (1u << 24) && !ctx->reuse_sort && !ctx->graphs_on && getenv("K16_ATOMIC_SORT") == nullptr &&
+                          getenv("K16_NO_FUSED_CONVERT") == nullptr;
+        if (fuse)
+            conv_in = d_bases;
+        else if ((rc = k16_msm_prepare_g1(ctx, d_bases, n, L.ws_conv.p, k16_lane_stream(ctx, ctx->cur_lane))))
+            return rc;
     }
-    return msm_enqueue_t<Eng9>(ctx, rows, d_scalars, n, c);
+    return msm_enqueue_t<Eng9>(ctx, rows, d_scalars, n, c, false, conv_in);
 }
 
 // ---- fixed-base window tables: row w*n + i = 2^(c*w) * P_i in the packed R' layout.
