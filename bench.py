@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native Groth16 hot path.
 
-Workload (BASELINE.json configs[1]): BN254 G1 Pippenger MSM, 2^20 points, uniform random scalars in
-[0, r), bases (i+1)*G -- all resident in HBM before the timed region.  One "step" = one complete MSM
-(digits -> bucket sort -> bucket accumulation -> weighted bucket reduction -> Horner combine ->
-XYZZ result on the host).  Steps are software-pipelined four deep over the context's MSM lanes (stream +
-workspace each): the kernels of steps k+1 .. k+3 are enqueued before step k is finished, so the latency-bound
-fold / reduction stages of one MSM overlap the next one's sort and accumulation and the 0.25 ms host tail is
-hidden; the timed region still contains exactly K complete MSMs, each fully reduced to one point.
+    python bench.py --gpus N --steps K --warmup W [--mode weak|strong] [--total-log2n 26] [--proofs P]
 
-    python bench.py --gpus N --steps K --warmup W
+Headline (`value`, BASELINE.json configs[1]): BN254 G1 Pippenger MSM, 2^20 points per GPU, uniform random scalars in
+[0, r), bases (i+1)*G -- all resident in HBM before the timed region.  One "step" = one complete MSM (digits -> bucket
+sort -> bucket accumulation -> weighted bucket reduction -> Horner combine -> XYZZ result on the host).  Steps are
+software-pipelined four deep over the context's MSM lanes (stream + workspace each); the timed region still contains
+exactly K complete MSMs, each fully reduced to one point, and the last result is checked (untimed) against the closed
+form  sum_i s_i (i+1) * G.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the MSM shards naturally,
-so every rank owns an independent 2^20-point shard of an N*2^20-point MSM (weak scaling), and each
-step ends with the path's one real exchange: an RCCL all_gather of the 128-byte per-shard partial
-results, folded on every rank with an EC add (RCCL has no EC-add reduction op).
+Multi-GPU.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before anything touches the GPU and
+exits with its return code (the driver's own torchrun launch is used as it is).  One rank per GPU over RCCL:
+  --mode weak   (default) every rank owns an independent 2^20-point shard of an N*2^20-point MSM; each step ends with the
+                path's one exchange, an all_gather of the 128-byte per-shard partial results + EC-add fold
+  --mode strong BASELINE config 5: ONE MSM of 2^total-log2n points (default 2^26), rank k takes
+                sharding.shard_range(2^26, N, k); same exchange; `scaling` = "strong"
 
-The JSON line also carries
-  roofline      -- for the dominant kernel (bucket accumulation): algorithmic bytes / measured launch time
-  cpu_baseline  -- the CPU oracle (oracle/, a port of the reference algorithm) timed on this host on a
-                   bounded sample of the same workload (rank 0, N = 1 only)
+The same JSON line also carries
+  proof         BASELINE config 3 / 4: full Groth16 proofs of a synthetic Keyless-shape key (nVars 1,343,588, N = 2^21,
+                8.3 M coefficients) on every rank (one prover per GPU, replicas): proofs/s over all ranks, p50 / p99
+                latency through k16_prover_prove_mem, and (world size 1) through the file-based C++ FullProver facade
+  roofline      for the dominant kernel (bucket accumulation): algorithmic bytes / measured launch time
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) timed on this host on the same MSM workload
+                and on ONE full proof of the same key, which is also the check of the GPU proof (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import struct
+import subprocess
 import sys
 import time
 
@@ -33,11 +40,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "keyless-zk-proofs_amd"))
 
 LOG2N = 20
+Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 ALGO_BYTES_PER_POINT = 64 + 32  # G1 MSM = n x (64 B affine point + 32 B scalar)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MODMUL_PER_PAIR = 10            # SURVEY 8(d) secondary figure: one mixed add (8M + 2S) per (point, window) pair
-MODMUL_PEAK_G = 174.3           # measured on MI355X: radix-2^29 Montgomery multiply, all CUs (profiles/r01/ubench_*.log)
+MODMUL_PEAK_G = 174.3           # measured on MI355X: radix-2^29 Montgomery multiply, all CUs (profiles/r02/ubench_fmul29.log)
+KEYLESS = dict(n_vars=1343588, n_public=1, domain=1 << 21, n_coefs=8300000)   # circuit/README.md:77-83, SURVEY 8(d)
 
 
 def uniform_scalars(n, seed):
@@ -60,12 +69,49 @@ def uniform_scalars(n, seed):
         out[bad] = rep
 
 
+def fast_scalars(n, seed):
+    """n x 32 B, uniform in [0, 2^253) (always < r): the generator for the 2^26-point strong-scaling leg, where the
+    rejection sampler above would take minutes on the host."""
+    g = np.random.default_rng(seed)
+    out = g.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + g.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    out[:, 3] &= np.uint64((1 << 61) - 1)
+    return out.view(np.uint8).reshape(n, 32)
+
+
+def weighted_sum_mod_r(scalars, start):
+    """sum_i s_i * (start + i + 1) mod r, exactly: the scalar k with MSM(s, bases (start+i+1)G) = k*G.
+    16-bit limbs of s times 14-bit halves of the weight, summed in u64 per 2^20-row chunk (no overflow: < 2^50)."""
+    n = scalars.shape[0]
+    total = 0
+    for lo in range(0, n, 1 << 20):
+        hi = min(n, lo + (1 << 20))
+        limbs = scalars[lo:hi].view("<u2").reshape(hi - lo, 16).astype(np.uint64)
+        w = np.arange(start + lo + 1, start + hi + 1, dtype=np.uint64)
+        for shift, part in ((0, w & np.uint64(0x3FFF)), (14, (w >> np.uint64(14)) & np.uint64(0x3FFF)), (28, w >> np.uint64(28))):
+            if not part.any():
+                continue
+            cols = part @ limbs           # 16 exact column sums
+            total += sum(int(cols[k]) << (16 * k) for k in range(16)) << shift
+    return total % R_MOD
+
+
+def scalar_times_g(ctx, k16, k):
+    """k*G through the library's own n = 1 path (Curve::mulByScalar's replacement) -- the closed-form side of the check."""
+    d_g = ctx.synth_points(k16.G1, 0, 1)
+    d_k = ctx.to_device(np.frombuffer(int(k).to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32))
+    _, aff = ctx.msm_device(k16.G1, d_g, d_k, 1)
+    d_g.free()
+    d_k.free()
+    return aff
+
+
+# ---------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(n_sample, scalars):
     """Times the CPU oracle (port of the reference's ParallelMultiexp) on the first n_sample points."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol  # the checker, used here only as the reported CPU baseline
 
-    threads = min(os.cpu_count() or 1, 16)  # the port parallelises over the 16 windows
+    threads = os.cpu_count() or 1   # the port parallelises over (window, point slice) pairs like the reference's TBB loop
     bases = ol.gen_points(0, 0, n_sample)
     sc = np.ascontiguousarray(scalars[:n_sample])
     ol.msm(0, bases[:4096], sc[:4096], nthreads=threads)  # warm-up
@@ -77,9 +123,189 @@ def cpu_baseline(n_sample, scalars):
         "unit": "points/s",
         "cores": threads,
         "kind": "port",
-        "sample": "first 2^%d points of the same workload, %.1f s wall, oracle/bn254_ref.c (gcc -O2, OpenMP over windows)"
+        "sample": "first 2^%d points of the same workload, %.1f s wall, oracle/bn254_ref.c (gcc -O2, OpenMP over "
+                  "windows x point slices, per-task bucket arrays + pack as multiexp.cpp:46-130)"
                   % (int(np.log2(n_sample)), dt),
     }
+
+
+# ---------------------------------------------------------------------------------------------------- proof leg
+def _le32(x):
+    return int(x).to_bytes(32, "little")
+
+
+def _section(t, payload):
+    return struct.pack("<IQ", t, len(payload)) + payload
+
+
+def synth_zkey_bytes(ctx, k16, n_vars, n_public, N, n_coefs, seed=1):
+    """Synthetic zkey of the Keyless SHAPE in the iden3 container the prover parses: points are
+    multiples of the generators made on the device, B1/B2 half (0,0), coefficients small values * R^2 in snarkjs order."""
+    rs = np.random.RandomState(seed)
+
+    def pts(group, start, n, zero_frac=0.0):
+        d = ctx.synth_points(group, start, n)
+        a = d.download(np.uint8, (n, k16.AFF_BYTES[group])).copy()
+        d.free()
+        if zero_frac > 0:
+            a[rs.rand(n) < zero_frac] = 0
+        return a.tobytes()
+
+    g1 = pts(k16.G1, 100, 3)
+    g2 = pts(k16.G2, 50, 3)
+    hdr = struct.pack("<I", 32) + _le32(Q_MOD) + struct.pack("<I", 32) + _le32(R_MOD) + struct.pack("<III", n_vars, n_public, N)
+    hdr += g1[0:64] + g1[64:128] + g2[0:128] + g2[128:256] + g1[128:192] + g2[256:384]
+    coef = np.zeros(n_coefs, dtype=[("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "V32")])
+    coef["m"] = rs.randint(0, 2, size=n_coefs)
+    coef["c"] = np.sort(rs.randint(0, N, size=n_coefs))
+    coef["s"] = rs.randint(0, n_vars, size=n_coefs)
+    r2 = pow(1 << 256, 2, R_MOD)
+    table = np.frombuffer(b"".join(_le32(v * r2 % R_MOD) for v in range(1, 257)), dtype="V32")
+    coef["v"] = table[rs.randint(0, 256, size=n_coefs)]
+    secs = [_section(1, struct.pack("<I", 1)), _section(2, hdr),
+            _section(4, struct.pack("<I", n_coefs) + coef.tobytes()),
+            _section(5, pts(k16.G1, 1000, n_vars)),
+            _section(6, pts(k16.G1, 3000000, n_vars, 0.5)),
+            _section(7, pts(k16.G2, 5000, n_vars, 0.5)),
+            _section(8, pts(k16.G1, 6000000, n_vars - n_public - 1)),
+            _section(9, pts(k16.G1, 9000000, N))]
+    return b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(secs)
+
+
+def synth_witness(n_vars, seed):
+    """90 % bits, 8 % bytes, 2 % full-width values; w[0] = 1."""
+    rs = np.random.RandomState(seed)
+    w = np.zeros((n_vars, 32), dtype=np.uint8)
+    u = rs.rand(n_vars)
+    bits = u < 0.90
+    w[bits, 0] = rs.randint(0, 2, size=int(bits.sum()))
+    byts = (u >= 0.90) & (u < 0.98)
+    w[byts, 0] = rs.randint(0, 256, size=int(byts.sum()))
+    full = u >= 0.98
+    f = rs.randint(0, 256, size=(int(full.sum()), 32), dtype=np.uint8)
+    f[:, 31] &= 0x1F
+    w[full] = f
+    w[0] = 0
+    w[0, 0] = 1
+    return w
+
+
+def write_wtns(path, w):
+    sec1 = struct.pack("<I", 32) + _le32(R_MOD) + struct.pack("<I", w.shape[0])
+    with open(path, "wb") as f:
+        f.write(b"wtns" + struct.pack("<II", 2, 2) + _section(1, sec1) + _section(2, w.tobytes()))
+
+
+def facade_leg(zpath, wpath, proofs):
+    """The file-based drop-in boundary: FullProver(zkey).prove(wtns_path) in a C++ process (tests/cpp/fullprover_harness.cpp,
+    what the Rust crate does through bindgen), timed by the harness around its prove() loop."""
+    pkg = os.path.join(ROOT, "keyless-zk-proofs_amd")
+    exe = os.path.join(pkg, "fullprover_harness")
+    if not os.path.exists(exe):      # build() makes it; fall back to compiling it here
+        exe = "/tmp/k16_fullprover_harness_%d" % os.getpid()
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "fullprover_harness.cpp"), "-L", pkg, "-lk16",
+                               "-Wl,-rpath," + pkg, "-pthread", "-o", exe])
+    out = subprocess.run([exe, zpath, wpath, str(proofs + 1)], capture_output=True, text=True, timeout=600)
+    lines = out.stdout.splitlines()
+    ms = [int(l.split("ms=")[1]) for l in lines if l.startswith("type=0 error=0")]
+    tot = [l for l in lines if l.startswith("elapsed_ms=")]
+    if out.returncode != 0 or len(ms) != proofs + 1 or not tot:
+        return {"error": "harness rc=%d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
+    # the first prove of a fresh process allocates the MSM workspaces: reported, not averaged in
+    elapsed = float(tot[0].split()[0].split("=")[1])
+    steady = (elapsed - ms[0]) if elapsed > ms[0] else elapsed
+    return {"proofs_per_s": proofs / (steady * 1e-3), "prover_time_ms_p50": float(np.median(ms[1:])),
+            "first_prove_ms": ms[0], "proofs": proofs,
+            "note": "FullProver(zkey).prove(path): mmap + parse of the 43 MB .wtns file inside every call; prover_time is "
+                    "the reference's own metric (RS/fullprover.cpp:226-244, whole milliseconds)"}
+
+
+def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, scale=1.0):
+    n_vars = max(int(KEYLESS["n_vars"] * scale), 8)
+    N = 1 << max(int(np.ceil(np.log2(max(1376867 * scale, 4)))), 2)
+    n_coefs = int(KEYLESS["n_coefs"] * scale)
+    t0 = time.time()
+    zk = synth_zkey_bytes(ctx, k16, n_vars, 1, N, n_coefs)
+    zpath = "/tmp/k16_bench_%d_%d.zkey" % (os.getpid(), rank)
+    with open(zpath, "wb") as f:
+        f.write(zk)
+    del zk
+    t_key = time.time() - t0
+    t0 = time.time()
+    prover = k16.Prover(ctx, zpath)
+    t_create = time.time() - t0
+    r, s = _le32(12345678901234567890 % R_MOD), _le32(98765432109876543210 % R_MOD)
+    wits = [synth_witness(n_vars, 100 + 16 * rank + i) for i in range(4)]
+    prover.prove_mem(wits[0], r, s)      # warm-up: workspace allocation
+    prover.prove_mem(wits[1], r, s)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    lat = []
+    t_all = time.perf_counter()
+    for i in range(proofs):
+        t1 = time.perf_counter()
+        prover.prove_mem(wits[i % len(wits)])          # production path: blinding drawn from the OS CSPRNG
+        lat.append((time.perf_counter() - t1) * 1e3)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_all
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        allv = [None] * world
+        dist.all_gather_object(allv, lat)
+        lat = [x for l in allv for x in l]
+    out = None
+    if rank == 0:
+        out = {"proofs_per_s": world * proofs / elapsed, "p50_ms": float(np.median(lat)),
+               "p99_ms": float(np.percentile(lat, 99)), "proofs": world * proofs, "entry": "k16_prover_prove_mem",
+               "n_vars": n_vars, "domain": N, "n_coefs": n_coefs, "n_public": 1,
+               "key": "synthetic, Keyless shape (the real zkey is not available offline); one resident copy per GPU",
+               "parallelism": "replicas: one prover per GPU, no collective" if world > 1 else "single GPU",
+               "setup_s": {"synthesize_key": t_key, "prover_create": t_create}, "checked": None}
+        wpath = "/tmp/k16_bench_%d.wtns" % os.getpid()
+        write_wtns(wpath, wits[0])
+        got = prover.prove_mem(wits[0], r, s)
+        if world == 1:
+            try:
+                out["facade"] = facade_leg(zpath, wpath, max(4, proofs // 2))
+            except Exception as e:
+                out["facade"] = {"error": repr(e)}
+        if check_with_oracle:
+            # ONE full proof by the CPU oracle on the same key, witness and injected (r, s): the CPU prover's time next to
+            # the GPU's, and the byte-for-byte check of the GPU proof
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as ol
+            threads = os.cpu_count() or 1
+            t0 = time.time()
+            want = ol.prove_files(zpath, wpath, r, s, nthreads=threads)
+            cpu_s = time.time() - t0
+            out["checked"] = bool(got == want)
+            out["cpu_oracle"] = {"seconds_per_proof": cpu_s, "proofs_per_s": 1.0 / cpu_s, "cores": threads, "kind": "port",
+                                 "sample": "one full proof of the same key and witness (oracle/bn254_ref.c groth16_prove)"}
+            if got != want:
+                raise SystemExit("bench.py: GPU proof differs from the CPU oracle's")
+        os.unlink(wpath)
+    prover.close()
+    os.unlink(zpath)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------- launch
+def spawn_ranks(args):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a child process.  Called before torch or the
+    HIP library is imported -- a process that has touched the GPU must never be replaced or re-launched."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -88,13 +314,21 @@ def main():
     ap.add_argument("--steps", type=int, default=100)   # 0.2 s of GPU time: long enough to amortise pipeline fill / drain
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=LOG2N)
+    ap.add_argument("--mode", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--total-log2n", type=int, default=26, help="strong mode: the whole MSM has 2^this points")
+    ap.add_argument("--proofs", type=int, default=20, help="full Keyless-shape proofs per rank in the proof leg (0: skip it)")
+    ap.add_argument("--proof-scale", type=float, default=1.0, help="shrink the synthetic circuit (1.0 = Keyless shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    n_gpus = max(args.gpus, 1)
+    if "WORLD_SIZE" not in os.environ and n_gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = max(args.gpus, 1)
+    if world != n_gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (n_gpus, world))
 
     # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Four MSM lanes fill
     # them; with torch.distributed the RCCL stream would have to share one with a lane (measured at world size 1:
@@ -115,31 +349,39 @@ def main():
     if world > 1 or os.environ.get("K16_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     dev = local_rank if world > 1 else 0
     ctx = k16.Context(dev)  # raises without a GPU / library: there is no CPU fallback
+    strong = args.mode == "strong"
+    depth_default = "1" if strong else "4"
     # steps are pipelined over the MSM lanes: throughput tuning (include/k16.h, K16_OPT_PIPELINED_MSM) -- 16 slots per
     # lane in the weighted bucket sum, and consecutive accumulations fenced so that the HIP events time execution only
-    if int(os.environ.get("K16_BENCH_DEPTH", "4")) > 1:
+    if int(os.environ.get("K16_BENCH_DEPTH", depth_default)) > 1:
         ctx.set_option(k16.OPT_PIPELINED_MSM, 1)
     # K16_BENCH_GRAPHS=1: the ~50 launches of an MSM's sort and reduction replayed as two HIP graphs (K16_OPT_GRAPHS).
     # Off by default: on ROCm 7.2 a hipGraphLaunch of ~25 nodes costs more host time than the launches it replaces
-    # (host_enqueue 0.14 -> 0.45 ms per MSM, 566 -> 470 M points/s)
     if os.environ.get("K16_BENCH_GRAPHS", "0") != "0":
         ctx.set_option(k16.OPT_GRAPHS, 1)
 
-    n = 1 << args.log2n
-    # this rank's shard of the (world * n)-point MSM: bases (rank*n + i + 1) * G, own scalars
-    d_bases = ctx.synth_points(k16.G1, rank * n, n)
-    scalars = uniform_scalars(n, seed=0xD1B5 + rank)
+    import sharding
+
+    if strong:
+        total = 1 << args.total_log2n
+        lo, hi = sharding.shard_range(total, world, rank)
+        n, start = hi - lo, lo
+        scalars = fast_scalars(n, seed=0xD1B5 + rank)
+    else:
+        n, start = 1 << args.log2n, rank * (1 << args.log2n)
+        scalars = uniform_scalars(n, seed=0xD1B5 + rank)
+    # this rank's shard: bases (start + i + 1) * G, own scalars
+    d_bases = ctx.synth_points(k16.G1, start, n)
     d_scalars = ctx.to_device(scalars)
 
     if os.environ.get("K16_BENCH_C"):           # experiments only: override the automatic window size
         ctx.set_window_bits(int(os.environ["K16_BENCH_C"]))
-
-    import sharding
 
     lane = [0]
 
@@ -161,8 +403,7 @@ def main():
 
     pending_x = []   # the previous step's exchange, still in flight
 
-    def finish():
-        xyzz, _ = ctx.msm_finish(k16.G1)   # waits for THIS MSM only, then conversion + Horner on the host
+    def exchange(xyzz):
         if dist is not None:
             # the path's one exchange: start this step's all_gather, complete the previous step's (it ran under the
             # GPU work enqueued in between); run() drains the last one inside the timed region
@@ -171,7 +412,12 @@ def main():
                 xyzz, _ = sharding.exchange_finish(pending_x.pop(0))
         return xyzz
 
-    depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", "4")), 4))]
+    def finish():
+        xyzz, _ = ctx.msm_finish(k16.G1)   # waits for THIS MSM only, then conversion + Horner on the host
+        return exchange(xyzz)
+
+    depth_cell = [max(1, min(int(os.environ.get("K16_BENCH_DEPTH", depth_default)), 4))]
+    chunked = n > (1 << 24)   # one device pass takes 2^24 points; above that k16_msm runs chunks on two lanes and folds them
 
     import threading
 
@@ -182,8 +428,11 @@ def main():
         waits.  K16_BENCH_THREADED=0: everything from this thread."""
         depth = depth_cell[0]
         res = None
+        if chunked:
+            for k in range(steps):
+                res = exchange(ctx.msm_device(k16.G1, d_bases, d_scalars, n)[0])
         # (not with torch.distributed: its Python-side calls and the producer then fight over the interpreter lock)
-        if depth == 1 or os.environ.get("K16_BENCH_THREADED", "1" if dist is None else "0") == "0":
+        elif depth == 1 or os.environ.get("K16_BENCH_THREADED", "1" if dist is None else "0") == "0":
             for k in range(min(depth - 1, steps)):
                 enqueue()
             for k in range(steps):
@@ -244,52 +493,87 @@ def main():
     saved_depth = depth_cell[0]
     depth_cell[0] = 1
     lane[0] = 0
-    run(3)
+    run(1 if chunked else 3)
     depth_cell[0] = saved_depth
     iso_launches, iso_ms = ctx.stats_get("msm_accumulate")
     stage_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
                 for k in ("msm_sort", "msm_accumulate", "msm_fold", "msm_reduce")}
     ctx.stats_enable(0)
 
+    ranks_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_seen = dist.get_world_size()
+
+    # untimed: the last step's (folded) result against the closed form  (sum over all shards of s_i * (start + i + 1)) * G
+    k_mine = weighted_sum_mod_r(scalars, start)
+    if dist is not None:
+        ks = [None] * ranks_seen
+        dist.all_gather_object(ks, k_mine)
+        k_all = sum(ks) % R_MOD
+    else:
+        k_all = k_mine
+    result_checked = None
+    if rank == 0:
+        _, got_aff = k16.points_sum(k16.G1, np.frombuffer(result, dtype=np.uint8).reshape(1, 128))
+        result_checked = bool(got_aff == scalar_times_g(ctx, k16, k_all))
+        if not result_checked:
+            raise SystemExit("bench.py: MSM result differs from the closed form sum s_i (i+1) * G")
+
+    # ---- the proof leg (every rank proves; rank 0 reports)
+    d_bases.free()
+    d_scalars.free()
+    proof = None
+    if args.proofs > 0:
+        proof = proof_leg(ctx, k16, torch, dist, rank, world, args.proofs,
+                          check_with_oracle=(world == 1 and not args.no_cpu_baseline), scale=args.proof_scale)
 
     if rank == 0:
-        total_points = float(n) * world * args.steps
+        total_points = float(n) * args.steps if not strong else float(1 << args.total_log2n) * args.steps
+        if not strong:
+            total_points *= world
         value = total_points / elapsed
         kern_s = (acc_ms / max(launches, 1)) * 1e-3
-        achieved = (n * ALGO_BYTES_PER_POINT) / kern_s / 1e9 if kern_s > 0 else 0.0
-        traffic = None
+        pts_per_launch = min(n, 1 << 24)
+        achieved = (pts_per_launch * ALGO_BYTES_PER_POINT) / kern_s / 1e9 if kern_s > 0 else 0.0
+        traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and not strong and args.log2n == 20:
             try:
                 traffic = json.load(open(tp)).get("msm_accumulate_hbm_bytes_per_launch")
+                traffic_src = "replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                              "command; not measured in this run)"
             except Exception:
                 traffic = None
+        iso = iso_ms / max(iso_launches, 1)
         out = {
-            "metric": "BN254 G1 MSM points/s @2^%d (Groth16 prover hot path)" % args.log2n,
+            "metric": "BN254 G1 MSM points/s @2^%d (Groth16 prover hot path)" % (args.total_log2n if strong else args.log2n),
             "value": value,
             "unit": "points/s",
-            "n_gpus": world if world > 1 else n_gpus,
+            "n_gpus": ranks_seen,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u64 column accumulators over 9 x 29-bit limbs (256-bit Montgomery integers, v_mad_u64_u32)",
-            "data": "synthetic: bases (i+1)*G generated on device, scalars uniform in [0,r) (numpy seed 0xD1B5+rank)",
+            "data": "synthetic: bases (i+1)*G generated on device, scalars uniform in [0,%s) (numpy seed 0xD1B5+rank)"
+                    % ("2^253" if strong else "r"),
+            "result_checked": result_checked,
             "config": {
-                "workload": "BN254 G1 Pippenger MSM, 2^%d random scalars/points per GPU, result XYZZ on host"
-                            % args.log2n,
+                "workload": ("BN254 G1 Pippenger MSM, ONE MSM of 2^%d points sharded over the ranks, result XYZZ on host"
+                             % args.total_log2n) if strong else
+                            ("BN254 G1 Pippenger MSM, 2^%d random scalars/points per GPU, result XYZZ on host" % args.log2n),
                 "points_per_gpu": n,
                 "bases": "fixed-base window tables (k16_msm_fixed_base_prepare)" if fixed_tab is not None
                          else "prepared once (k16_msm_bases_prepare)" if prepared is not None
                          else "reference format (Montgomery affine), converted inside every step",
-                "sharding": "independent contiguous shards + RCCL all_gather of 128-B partials" if world > 1
-                            else "single GPU",
+                "sharding": "contiguous shards (sharding.shard_range) + RCCL all_gather of 128-B partials + EC-add fold"
+                            if dist is not None else "single GPU",
             },
             "roofline": {
                 "kernel": "k_accumulate<Eng9> (bucket accumulation, XYZZ mixed adds)",
@@ -299,37 +583,41 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel_ms": kern_s * 1e3,
-                "kernel_ms_isolated": iso_ms / max(iso_launches, 1),
-                "frac_isolated": (n * ALGO_BYTES_PER_POINT) / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                 if iso_ms > 0 else None,
+                "kernel_ms_isolated": iso,
+                "frac_isolated": (pts_per_launch * ALGO_BYTES_PER_POINT) / (iso * 1e-3) / 1e9 / HBM_PEAK_GBS if iso > 0 else None,
                 # the same launch priced in the unit that actually bounds it: 254-bit modular multiplications
                 "alu": {
                     "unit": "G modmul/s",
-                    "achieved": n * 16 * MODMUL_PER_PAIR / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 if iso_ms > 0 else None,
+                    "achieved": pts_per_launch * 16 * MODMUL_PER_PAIR / (iso * 1e-3) / 1e9 if iso > 0 else None,
                     "peak": MODMUL_PEAK_G,
-                    "frac": n * 16 * MODMUL_PER_PAIR / (iso_ms / max(iso_launches, 1) * 1e-3) / 1e9 / MODMUL_PEAK_G
-                            if iso_ms > 0 else None,
+                    "frac": pts_per_launch * 16 * MODMUL_PER_PAIR / (iso * 1e-3) / 1e9 / MODMUL_PEAK_G if iso > 0 else None,
                     "basis": "algorithmic 10 modmul x n x 16 windows per launch / kernel_ms_isolated; peak = measured "
                              "v_mad_u64_u32-bound multiply rate of the radix-2^29 field (no MFMA path exists for 254-bit integers)",
                 },
                 "note": "kernel_ms is the live average inside the timed region (HIP events on the kernel's stream; up to "
-                        "three MSMs share the GPU, so the other lanes' sort / reduction kernels run beside it); "
+                        "four MSMs share the GPU, so the other lanes' sort / reduction kernels run beside it); "
                         "kernel_ms_isolated is the same kernel with one MSM at a time. Integer-multiply-issue bound in "
                         "practice; see DESIGN.md (modmul-rate view)",
             },
             "stage_ms_isolated": stage_ms,
             "host_ms": host_ms,
+            "proof": proof,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(1 << min(args.log2n, 20), scalars)
+                n_cpu = 1 << min(args.log2n, 20)
+                out["cpu_baseline"] = cpu_baseline(n_cpu, uniform_scalars(n_cpu, seed=0xD1B5) if strong else scalars)
+                if proof and proof.get("cpu_oracle"):
+                    out["cpu_baseline"]["proof"] = proof.pop("cpu_oracle")
             except Exception as e:  # the baseline is a report, never the measured path
                 out["cpu_baseline"] = {"value": None, "unit": "points/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
 
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 

@@ -47,6 +47,16 @@ enum {
 
 enum { K16_G1 = 0, K16_G2 = 1 };
 enum { K16_FQ = 0, K16_FR = 1 };
+/* Selectors for k16_field_op_vec / k16_point_op_vec only: the SAME inputs and outputs (the reference's canonical
+ * Montgomery form), but the operation runs on the representation the hot kernels use -- the unsaturated radix-2^29
+ * field of bn254_fq9.h (Fq9 for G1, Fr9 for the NTT chain, Fq2n = Fq2 over Fq9 for G2; elements of K16_FQ2N are 64 B:
+ * a | b) and the Eng9 / Eng2n point formulas of the MSM kernels.  Values are converted at the edges, exactly.
+ * For these selectors bits 8-11 / 12-15 of `op` add that many multiples of the modulus to operand a / b after the
+ * conversion (operands at the documented bounds: X < 8p, Y < 4p, ZZ < 2p ...); the result must not change. */
+enum { K16_FQ9 = 2, K16_FR9 = 3, K16_FQ2N = 4 };
+enum { K16_G1_ENG9 = 2, K16_G2_ENG2N = 3 };
+#define K16_OP_BOUND_A(k) ((k) << 8)
+#define K16_OP_BOUND_B(k) ((k) << 12)
 enum { K16_OP_ADD = 0, K16_OP_SUB, K16_OP_NEG, K16_OP_MUL, K16_OP_SQR, K16_OP_TOMONT, K16_OP_FROMMONT };
 enum { K16_PT_ADD = 0, K16_PT_MADD, K16_PT_DBL };
 
@@ -102,6 +112,14 @@ int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const void* h_sca
  * k16_msm_finish() synchronises, downloads them and does the final Horner combine on the host. */
 int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n);
 int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine);
+/* k16_msm_finish for a caller that knows which group the oldest MSM in flight belongs to: fails with K16_ERR_ARG and
+ * consumes nothing when it is the other one (a G2 result is 256 bytes; it must never land in a 128-byte G1 buffer). */
+int k16_msm_finish_group(k16_ctx* ctx, int group, void* h_out_xyzz, void* h_out_affine);
+/* number of MSMs enqueued and not yet finished (0 .. 8), negative on error */
+int k16_msm_pending(k16_ctx* ctx);
+/* error recovery: waits for and drops every MSM in flight, clears sort-reuse / lane state (the prover does this on
+ * every failed prove so that a later prove never pops a stale result) */
+int k16_msm_abort_all(k16_ctx* ctx);
 /* Static point tables (the zkey's sections 5-9) can be prepared once: d_out (same size as d_bases)
  * receives the rows in the layout the accumulate kernel gathers from (G1: x*2^261, y*2^261 mod p packed
  * in 2 x 32 B -- the Montgomery form of the kernels' radix-2^29 field; G2: the same per Fq2 component).  A prepared

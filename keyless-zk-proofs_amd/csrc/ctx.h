@@ -118,6 +118,11 @@ struct k16_ctx {
     // 16 (4) does 12 % less reduction work with chains twice as long -- +5 % for pipelined MSMs, +4 % latency for one
     unsigned    wsum_mlog_cap = 3;
     hipEvent_t  last_acc_done = nullptr;
+    // Unused dynamic LDS requested for the bucket accumulation, to cap ITS occupancy (K16_ACC_LDS, bytes per 128-thread
+    // workgroup: 36864 -> 4 workgroups = 2 waves/SIMD per CU instead of the 3 its 159 VGPRs allow).  The registers a
+    // third wave would take stay free for the other lanes' sort / fold / reduction kernels, which otherwise wait for a
+    // whole accumulate workgroup to retire before one of their waves fits.
+    unsigned    acc_lds_bytes = 0;
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };

@@ -1,7 +1,9 @@
 // ctx.hip -- context, device memory, timers, and the batch field / point kernels used by the
 // parity tests of the device arithmetic (fq_raw_generic.cpp:12-233, curve.cpp:91-458).
 #include <string.h>
+#include <algorithm>
 #include "ctx.h"
+#include "bn254_fq9.h"
 
 using namespace k16;
 
@@ -38,6 +40,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
     if (const char* e = getenv("K16_WSUM_MLOG_CAP")) c->wsum_mlog_cap = (unsigned)atoi(e);
     if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
+    if (const char* e = getenv("K16_ACC_LDS")) c->acc_lds_bytes = (unsigned)std::min(65536, std::max(0, atoi(e)));
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
@@ -140,6 +143,7 @@ extern "C" int k16_dev_alloc(k16_ctx* c, size_t bytes, void** dptr)
 extern "C" int k16_dev_free(k16_ctx* c, void* dptr)
 {
     if (!c) return K16_ERR_ARG;
+    K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipDeviceSynchronize());
     K16_HIP(c, hipFree(dptr));
     return K16_OK;
@@ -147,6 +151,7 @@ extern "C" int k16_dev_free(k16_ctx* c, void* dptr)
 extern "C" int k16_h2d(k16_ctx* c, void* d, const void* h, size_t bytes)
 {
     if (!c) return K16_ERR_ARG;
+    K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     K16_HIP(c, hipStreamSynchronize(c->stream));
     return K16_OK;
@@ -154,6 +159,7 @@ extern "C" int k16_h2d(k16_ctx* c, void* d, const void* h, size_t bytes)
 extern "C" int k16_d2h(k16_ctx* c, void* h, const void* d, size_t bytes)
 {
     if (!c) return K16_ERR_ARG;
+    K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     K16_HIP(c, hipStreamSynchronize(c->stream));
     return K16_OK;
@@ -267,6 +273,128 @@ __global__ void k_point_op(int op, const Xyzz<F>* __restrict__ p1, const void* _
     r[i] = z;
 }
 
+
+// ---- the same batch operations on the representations the HOT kernels use (K16_FQ9 / K16_FR9 / K16_FQ2N,
+// K16_G1_ENG9 / K16_G2_ENG2N): canonical values in and out, converted exactly at the edges, the operation itself on
+// the unsaturated radix-2^29 field (bn254_fq9.h) / the Eng9 and Eng2n point formulas of msm_kernels.inc.
+template <class C>
+__device__ __forceinline__ Fq9 add_kp(Fq9 a, unsigned k)
+{
+    Fq9 pp;
+#pragma unroll
+    for (int i = 0; i < 9; i++) pp.l[i] = C::P[i];
+    for (unsigned j = 0; j < k; j++) a = fadd9(a, pp);
+    return a;
+}
+template <class C, class PR>
+__device__ __forceinline__ Fq9 f9_in(const Fp<PR>& x)
+{
+    Fq9 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = C::K_IN[i];
+    return fmul9_t<C>(fq9_unpack(x.v), k); // x*R -> x*R' , < 2p
+}
+template <class C, class PR>
+__device__ __forceinline__ Fp<PR> f9_out(const Fq9& a) // any bound <= 12p
+{
+    Fq9 k;
+#pragma unroll
+    for (int i = 0; i < 9; i++) k.l[i] = C::K_OUT[i];
+    Fq9    v = fmul9_t<C>(a, k);
+    Fp<PR> r;
+    fq9_pack(r.v, v);
+    cond_sub_p<PR>(r.v);
+    return r;
+}
+template <class C, class PR>
+__global__ void k_field_op9(int op, unsigned ka, unsigned kb, const Fp<PR>* __restrict__ a, const Fp<PR>* __restrict__ b,
+                            Fp<PR>* __restrict__ r, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fp<PR> xa = a[i], xb = b ? b[i] : Fp<PR>::zero();
+    Fq9          x = add_kp<C>(f9_in<C, PR>(xa), ka), y = add_kp<C>(f9_in<C, PR>(xb), kb);
+    Fp<PR>       z;
+    switch (op) {
+    case K16_OP_ADD: z = f9_out<C, PR>(fadd9(x, y)); break;                       // < 4 + ka + kb
+    case K16_OP_SUB: z = f9_out<C, PR>(fsub9_t<C, 8>(x, y)); break;               // needs 2 + kb <= 8
+    case K16_OP_NEG: z = f9_out<C, PR>(fsub9_t<C, 8>(fq9_zero(), x)); break;
+    case K16_OP_MUL: z = f9_out<C, PR>(fmul9_t<C>(x, y)); break;                  // needs (2+ka)(2+kb) <= 128
+    case K16_OP_SQR: z = f9_out<C, PR>(fsqr9_t<C>(x)); break;
+    case K16_OP_TOMONT: { // x*R: ((x/R)*R') * R^2 / R'
+        Fp<PR> r2 = Fp<PR>::r2();
+        Fq9    v  = fmul9_t<C>(x, fq9_unpack(r2.v));
+        fq9_pack(z.v, v);
+        cond_sub_p<PR>(z.v);
+    } break;
+    case K16_OP_FROMMONT: { // x/R: ((x/R)*R') * 1 / R'   (what fr9_to_standard does for the H scalars)
+        Fq9 one = fq9_zero();
+        one.l[0] = 1;
+        Fq9 v = fmul9_t<C>(x, one);
+        fq9_pack(z.v, v);
+        cond_sub_p<PR>(z.v);
+    } break;
+    default: z = Fp<PR>::zero();
+    }
+    r[i] = z;
+}
+__global__ void k_field_op_fq2n(int op, const Fq2* __restrict__ a, const Fq2* __restrict__ b, Fq2* __restrict__ r, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fq2n x = fq2n_from_canonical(a[i]), y = fq2n_from_canonical(b ? b[i] : Fq2::zero()), z;
+    switch (op) {
+    case K16_OP_ADD: z = fadd(x, y); break;
+    case K16_OP_SUB: z = fsub(x, y); break;
+    case K16_OP_NEG: z = fneg(x); break;
+    case K16_OP_MUL: z = fmul(x, y); break;
+    case K16_OP_SQR: z = fsqr(x); break;
+    default: z = Fq2n::zero();
+    }
+    r[i] = fq2n_to_canonical(z);
+}
+// p1 gets X += 3*ka*p, Y += ka*p (ka <= 2: X < 8p, Y < 4p, the documented bounds of a stored Xyzz9); p2 likewise with
+// kb when it is an XYZZ point (an affine row must stay < 2p)
+__global__ void k_point_op_eng9(int op, unsigned ka, unsigned kb, const G1Xyzz* __restrict__ p1, const void* __restrict__ p2,
+                                G1Xyzz* __restrict__ r, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto in9 = [](const G1Xyzz& p, unsigned k) {
+        return Xyzz9{add_kp<Fq9C>(fq9_from_fq(p.x), 3 * k), add_kp<Fq9C>(fq9_from_fq(p.y), k), fq9_from_fq(p.zz),
+                     fq9_from_fq(p.zzz)};
+    };
+    Xyzz9 a = in9(p1[i], ka), z;
+    switch (op) {
+    case K16_PT_ADD: z = padd9(a, in9(((const G1Xyzz*)p2)[i], kb)); break;
+    case K16_PT_MADD: z = padd_mixed9(a, aff9_from_canonical(((const G1Aff*)p2)[i])); break;
+    case K16_PT_DBL: z = pdbl9(a); break;
+    default: z = Xyzz9::zero();
+    }
+    r[i] = G1Xyzz{fq9_to_fq(z.x), fq9_to_fq(z.y), fq9_to_fq(z.zz), fq9_to_fq(z.zzz)}; // coordinate by coordinate
+}
+__global__ void __launch_bounds__(64) k_point_op_eng2n(int op, const G2Xyzz* __restrict__ p1, const void* __restrict__ p2,
+                                                       G2Xyzz* __restrict__ r, uint64_t n)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto in2 = [](const G2Xyzz& p) {
+        return Xyzz<Fq2n>{fq2n_from_canonical(p.x), fq2n_from_canonical(p.y), fq2n_from_canonical(p.zz),
+                          fq2n_from_canonical(p.zzz)};
+    };
+    Xyzz<Fq2n> a = in2(p1[i]), z;
+    switch (op) {
+    case K16_PT_ADD: z = padd(a, in2(((const G2Xyzz*)p2)[i])); break;
+    case K16_PT_MADD: {
+        G2Aff q = ((const G2Aff*)p2)[i];
+        z = padd_mixed(a, Aff<Fq2n>{fq2n_from_canonical(q.x), fq2n_from_canonical(q.y)});
+    } break;
+    case K16_PT_DBL: z = pdbl(a); break;
+    default: z = Xyzz<Fq2n>::zero();
+    }
+    r[i] = G2Xyzz{fq2n_to_canonical(z.x), fq2n_to_canonical(z.y), fq2n_to_canonical(z.zz), fq2n_to_canonical(z.zzz)};
+}
+
 // Synthetic point table: out[i] = (start + i + 1) * G, affine Montgomery -- the deterministic bases of
 // SURVEY 8(d) (the reference's own MSM test uses the same family, alt_bn128_test.cpp:183-190).
 template <class F>
@@ -323,10 +451,15 @@ extern "C" int k16_synth_points(k16_ctx* c, int group, uint64_t start, uint64_t 
 
 extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n)
 {
-    if (!c || !h_a || !h_r || (field != K16_FQ && field != K16_FR)) return K16_ERR_ARG;
+    if (!c || !h_a || !h_r || field < K16_FQ || field > K16_FQ2N) return K16_ERR_ARG;
+    const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
+    op &= 0xff;
+    if ((ka || kb) && (field < K16_FQ9 || field == K16_FQ2N || ka > 6 || kb > 6)) return K16_ERR_ARG;
+    if (field == K16_FQ2N && op > K16_OP_SQR) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
+    K16_HIP(c, hipSetDevice(c->device));
     void * da = nullptr, *db = nullptr, *dr = nullptr;
-    size_t bytes = (size_t)n * 32;
+    size_t bytes = (size_t)n * (field == K16_FQ2N ? 64 : 32);
     K16_HIP(c, hipMalloc(&da, bytes));
     K16_HIP(c, hipMalloc(&dr, bytes));
     K16_HIP(c, hipMemcpyAsync(da, h_a, bytes, hipMemcpyHostToDevice, c->stream));
@@ -338,9 +471,18 @@ extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, 
     if (field == K16_FQ)
         hipLaunchKernelGGL((k_field_op<FqParams>), dim3(grid), dim3(256), 0, c->stream, op, (const Fq*)da,
                            (const Fq*)db, (Fq*)dr, n);
-    else
+    else if (field == K16_FR)
         hipLaunchKernelGGL((k_field_op<FrParams>), dim3(grid), dim3(256), 0, c->stream, op, (const Fr*)da,
                            (const Fr*)db, (Fr*)dr, n);
+    else if (field == K16_FQ9)
+        hipLaunchKernelGGL((k_field_op9<Fq9C, FqParams>), dim3(grid), dim3(256), 0, c->stream, op, ka, kb, (const Fq*)da,
+                           (const Fq*)db, (Fq*)dr, n);
+    else if (field == K16_FR9)
+        hipLaunchKernelGGL((k_field_op9<Fr9C, FrParams>), dim3(grid), dim3(256), 0, c->stream, op, ka, kb, (const Fr*)da,
+                           (const Fr*)db, (Fr*)dr, n);
+    else
+        hipLaunchKernelGGL(k_field_op_fq2n, dim3(grid), dim3(256), 0, c->stream, op, (const Fq2*)da, (const Fq2*)db,
+                           (Fq2*)dr, n);
     K16_HIP(c, hipGetLastError());
     K16_HIP(c, hipMemcpyAsync(h_r, dr, bytes, hipMemcpyDeviceToHost, c->stream));
     K16_HIP(c, hipStreamSynchronize(c->stream));
@@ -353,10 +495,15 @@ extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, 
 extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1, const void* h_p2, void* h_r,
                                 uint64_t n)
 {
-    if (!c || !h_p1 || !h_r || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+    if (!c || !h_p1 || !h_r || group < K16_G1 || group > K16_G2_ENG2N) return K16_ERR_ARG;
+    const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
+    op &= 0xff;
+    if ((ka || kb) && (group != K16_G1_ENG9 || ka > 2 || kb > 2 || (kb && op != K16_PT_ADD))) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
-    size_t xb  = group == K16_G1 ? sizeof(G1Xyzz) : sizeof(G2Xyzz);
-    size_t ab  = group == K16_G1 ? sizeof(G1Aff) : sizeof(G2Aff);
+    K16_HIP(c, hipSetDevice(c->device));
+    const bool g1 = group == K16_G1 || group == K16_G1_ENG9;
+    size_t xb  = g1 ? sizeof(G1Xyzz) : sizeof(G2Xyzz);
+    size_t ab  = g1 ? sizeof(G1Aff) : sizeof(G2Aff);
     size_t p2b = (op == K16_PT_MADD) ? ab : xb;
     void * d1 = nullptr, *d2 = nullptr, *dr = nullptr;
     K16_HIP(c, hipMalloc(&d1, n * xb));
@@ -370,8 +517,14 @@ extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1,
     if (group == K16_G1)
         hipLaunchKernelGGL((k_point_op<Fq>), dim3(grid), dim3(64), 0, c->stream, op, (const G1Xyzz*)d1, d2,
                            (G1Xyzz*)dr, n);
-    else
+    else if (group == K16_G2)
         hipLaunchKernelGGL((k_point_op<Fq2>), dim3(grid), dim3(64), 0, c->stream, op, (const G2Xyzz*)d1, d2,
+                           (G2Xyzz*)dr, n);
+    else if (group == K16_G1_ENG9)
+        hipLaunchKernelGGL(k_point_op_eng9, dim3(grid), dim3(64), 0, c->stream, op, ka, kb, (const G1Xyzz*)d1, d2,
+                           (G1Xyzz*)dr, n);
+    else
+        hipLaunchKernelGGL(k_point_op_eng2n, dim3(grid), dim3(64), 0, c->stream, op, (const G2Xyzz*)d1, d2,
                            (G2Xyzz*)dr, n);
     K16_HIP(c, hipGetLastError());
     K16_HIP(c, hipMemcpyAsync(h_r, dr, n * xb, hipMemcpyDeviceToHost, c->stream));

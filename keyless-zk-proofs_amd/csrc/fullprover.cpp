@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/k16.h"
@@ -60,9 +61,12 @@ public:
     struct Slot {
         k16_ctx*    ctx    = nullptr;
         k16_prover* prover = nullptr;
+        int         device = 0;
         bool        busy   = false;
+        bool        dead   = false; // a device fault hit this slot and rebuilding it failed: never handed out again
     };
     std::vector<Slot>       slots;
+    std::string             zkey_path; // to rebuild a slot after a device fault
     std::mutex              mu;
     std::condition_variable cv;
 
@@ -73,17 +77,39 @@ public:
             if (s.ctx) k16_ctx_destroy(s.ctx);
         }
     }
-    // blocks until a prover is free; proofs of concurrent callers run on different slots
+    // blocks until a prover is free; proofs of concurrent callers run on different slots.  nullptr: every slot is dead.
     Slot* acquire()
     {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            for (Slot& s : slots)
+            bool any_alive = false;
+            for (Slot& s : slots) {
+                if (s.dead) continue;
+                any_alive = true;
                 if (!s.busy) {
                     s.busy = true;
                     return &s;
                 }
+            }
+            if (!any_alive) return nullptr;
             cv.wait(lk);
+        }
+    }
+    // A HIP error during a proof (device fault, failed allocation, lost context) leaves the slot's context in an unknown
+    // state: it is torn down and rebuilt from the key file in a fresh context before anybody else gets it.  If that
+    // fails too the slot is marked dead; the other slots of the pool keep serving.
+    void quarantine(Slot* s)
+    {
+        if (s->prover) k16_prover_destroy(s->prover);
+        if (s->ctx) k16_ctx_destroy(s->ctx);
+        s->prover = nullptr;
+        s->ctx    = nullptr;
+        if (k16_ctx_create(s->device, &s->ctx) != K16_OK || k16_prover_create(s->ctx, zkey_path.c_str(), &s->prover) != K16_OK) {
+            fprintf(stderr, "k16 FullProver: device %d could not be re-initialised after a fault; slot retired\n", s->device);
+            if (s->ctx) k16_ctx_destroy(s->ctx);
+            s->ctx = nullptr;
+            std::lock_guard<std::mutex> lk(mu);
+            s->dead = true;
         }
     }
     void release(Slot* s)
@@ -92,7 +118,7 @@ public:
             std::lock_guard<std::mutex> lk(mu);
             s->busy = false;
         }
-        cv.notify_one();
+        cv.notify_all(); // also wakes waiters when the last live slot died
     }
 };
 
@@ -116,26 +142,36 @@ ProverResponse::~ProverResponse()
 FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullProverState::ZKEY_FILE_LOAD_ERROR)
 {
     if (!_zkeyFileName) return;
-    FullProverImpl* p = new (std::nothrow) FullProverImpl();
-    if (!p) return;
-    for (int dev : device_list()) {
-        FullProverImpl::Slot s;
-        if (k16_ctx_create(dev, &s.ctx) != K16_OK) {
-            fprintf(stderr, "k16 FullProver: no usable MI355X / HIP device %d; the prover has no CPU fallback\n", dev);
-            delete p;
-            return;
+    FullProverImpl* p = nullptr;
+    // nothing may throw across the FFI (bindgen callers cannot catch): allocation failures inside the std containers
+    // used here and below end as ZKEY_FILE_LOAD_ERROR
+    try {
+        p            = new FullProverImpl();
+        p->zkey_path = _zkeyFileName;
+        for (int dev : device_list()) {
+            FullProverImpl::Slot s;
+            s.device = dev;
+            if (k16_ctx_create(dev, &s.ctx) != K16_OK) {
+                fprintf(stderr, "k16 FullProver: no usable MI355X / HIP device %d; the prover has no CPU fallback\n", dev);
+                delete p;
+                return;
+            }
+            int rc = k16_prover_create(s.ctx, _zkeyFileName, &s.prover);
+            if (rc != K16_OK) {
+                // fullprover.cpp:91-100 : invalid_argument -> UNSUPPORTED_ZKEY_CURVE, system_error -> ZKEY_FILE_LOAD_ERROR
+                state = (rc == K16_ERR_CURVE || rc == K16_ERR_FORMAT) ? FullProverState::UNSUPPORTED_ZKEY_CURVE
+                                                                      : FullProverState::ZKEY_FILE_LOAD_ERROR;
+                if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) fprintf(stderr, "k16 FullProver: %s\n", k16_last_error(s.ctx));
+                k16_ctx_destroy(s.ctx);
+                delete p;
+                return;
+            }
+            p->slots.push_back(s);
         }
-        int rc = k16_prover_create(s.ctx, _zkeyFileName, &s.prover);
-        if (rc != K16_OK) {
-            // fullprover.cpp:91-100 : invalid_argument -> UNSUPPORTED_ZKEY_CURVE, system_error -> ZKEY_FILE_LOAD_ERROR
-            state = (rc == K16_ERR_CURVE || rc == K16_ERR_FORMAT) ? FullProverState::UNSUPPORTED_ZKEY_CURVE
-                                                                  : FullProverState::ZKEY_FILE_LOAD_ERROR;
-            if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) fprintf(stderr, "k16 FullProver: %s\n", k16_last_error(s.ctx));
-            k16_ctx_destroy(s.ctx);
-            delete p;
-            return;
-        }
-        p->slots.push_back(s);
+    } catch (...) {
+        delete p;
+        state = FullProverState::ZKEY_FILE_LOAD_ERROR;
+        return;
     }
     impl  = p;
     state = FullProverState::OK;
@@ -150,27 +186,41 @@ ProverResponse FullProver::prove(const char* input) const
 {
     if (state != FullProverState::OK || !impl) return ProverResponse(ProverError::PROVER_NOT_READY);
     if (!input) return ProverResponse(ProverError::INVALID_INPUT);
-    log_line("INFO", "FullProver::prove begin");
-    char  json[2048];
-    float dev_ms = 0;
-    FullProverImpl::Slot* slot = impl->acquire();
-    auto  t0     = std::chrono::high_resolution_clock::now();
-    int   rc     = k16_prover_prove_file(slot->prover, input, nullptr, nullptr, json, sizeof json, &dev_ms);
-    auto  t1     = std::chrono::high_resolution_clock::now();
-    if (rc < 0 && rc != K16_ERR_CURVE && log_on())
-        fprintf(stderr, "k16 FullProver::prove failed: %s\n", k16_last_error(slot->ctx));
-    impl->release(slot);
-    if (rc == K16_ERR_CURVE) {
-        log_line("ERROR", "witness file uses a different curve than bn128");
-        return ProverResponse(ProverError::WITNESS_GENERATION_INVALID_CURVE);
+    try {
+        log_line("INFO", "FullProver::prove begin");
+        char  json[2048];
+        float dev_ms = 0;
+        FullProverImpl::Slot* slot = impl->acquire();
+        if (!slot) return ProverResponse(ProverError::PROVER_NOT_READY); // every device of the pool has been retired
+        auto  t0     = std::chrono::high_resolution_clock::now();
+        int   rc     = k16_prover_prove_file(slot->prover, input, nullptr, nullptr, json, sizeof json, &dev_ms);
+        auto  t1     = std::chrono::high_resolution_clock::now();
+        if (rc < 0 && rc != K16_ERR_CURVE && log_on())
+            fprintf(stderr, "k16 FullProver::prove failed: %s\n", k16_last_error(slot->ctx));
+        // A HIP failure is the DEVICE's fault, not the caller's: PROVER_NOT_READY (the service's retry / failover class,
+        // RS/fullprover.cpp:117-121), and the slot goes back into the pool only after it has been rebuilt
+        if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) impl->quarantine(slot);
+        impl->release(slot);
+        if (rc == K16_ERR_CURVE) {
+            log_line("ERROR", "witness file uses a different curve than bn128");
+            return ProverResponse(ProverError::WITNESS_GENERATION_INVALID_CURVE);
+        }
+        if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) {
+            log_line("ERROR", "device fault during prove; prover slot re-initialised");
+            return ProverResponse(ProverError::PROVER_NOT_READY);
+        }
+        if (rc < 0) return ProverResponse(ProverError::INVALID_INPUT);
+        ProverResponseMetrics m;
+        m.prover_time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
+        if (log_on()) {
+            char line[128];
+            snprintf(line, sizeof line, "Time taken for Groth16 prover: %d milliseconds (device %.3f ms)", m.prover_time, dev_ms);
+            log_line("INFO", line);
+        }
+        char* copy = strdup(json);
+        if (!copy) return ProverResponse(ProverError::PROVER_NOT_READY);
+        return ProverResponse(copy, m);
+    } catch (...) { // std::bad_alloc / std::system_error from the pool's mutex: never across the FFI
+        return ProverResponse(ProverError::PROVER_NOT_READY);
     }
-    if (rc < 0) return ProverResponse(ProverError::INVALID_INPUT);
-    ProverResponseMetrics m;
-    m.prover_time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
-    if (log_on()) {
-        char line[128];
-        snprintf(line, sizeof line, "Time taken for Groth16 prover: %d milliseconds (device %.3f ms)", m.prover_time, dev_ms);
-        log_line("INFO", line);
-    }
-    return ProverResponse(strdup(json), m);
 }

@@ -3,6 +3,7 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <string>
 #include <vector>
 #include "ctx.h"
 #include "bn254_fq9.h"
@@ -192,9 +193,9 @@ struct HostTimer {
 
 static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, int prepared)
 {
+    if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     HostTimer ht(ctx, "host_enqueue");
     K16_HIP(ctx, hipSetDevice(ctx->device)); // the calling thread may be new (bench.py enqueues from a second thread)
-    if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n >= (1ull << 32) / 80) { // index / offset arithmetic is 32-bit: n * W must stay below 2^32
         ctx->err = "k16_msm: n too large for one device call; shard it";
         return K16_ERR_ARG;
@@ -249,19 +250,32 @@ extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_base
     return k16_msm_prepare_g2(ctx, d_bases, n, d_out, nullptr);
 }
 
-extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
+// The head entry stays in the ring (pend_count unchanged) until its staged partial sums have been copied out of the
+// pinned slot: an enqueuing thread computes its slot as (head + count) % PEND_SLOTS, so popping first would let it
+// re-record the event and queue a download into the slot this thread is still waiting on / reading.
+// expect_group >= 0: fail (without consuming anything) when the head MSM is of the other group -- a G2 result is 256
+// bytes and must never be written into a caller's 128-byte G1 buffer.
+static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void* h_out_affine)
 {
     if (!ctx) return K16_ERR_ARG;
     k16_ctx::Pend pd;
     {
         std::lock_guard<std::mutex> lk(ctx->ring_mu);
         if (ctx->pend_count == 0) return K16_ERR_ARG;
-        pd             = ctx->pend[ctx->pend_head];
+        pd = ctx->pend[ctx->pend_head];
+        if (expect_group >= 0 && pd.group != expect_group) {
+            ctx->err = "k16_msm_finish: the oldest MSM in flight belongs to the other group";
+            return K16_ERR_ARG;
+        }
+    }
+    auto pop = [&]() {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
         ctx->pend_head = (ctx->pend_head + 1) % k16_ctx::PEND_SLOTS;
         ctx->pend_count--;
-    }
+    };
     const int group = pd.group;
     if (pd.n == 0) {
+        pop();
         if (group == K16_G1) {
             G1Xyzz z = G1Xyzz::zero();
             if (h_out_xyzz) memcpy(h_out_xyzz, &z, sizeof z);
@@ -275,7 +289,13 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
     }
     {
         HostTimer hw(ctx, "host_finish_wait");
-        K16_HIP(ctx, hipEventSynchronize(ctx->pend_ev[pd.slot])); // only this MSM's results; later ones keep running
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->pend_ev[pd.slot]); // only this MSM's results; later ones keep running
+        if (e != hipSuccess) {
+            pop(); // the entry is consumed either way: a failed MSM must not be handed to the next caller
+            ctx->err = std::string("k16_msm_finish: ") + hipGetErrorString(e);
+            return K16_ERR_HIP;
+        }
     }
     HostTimer hc(ctx, "host_finish_combine");
     const char*    src = (const char*)ctx->pinned + (size_t)pd.slot * k16_ctx::SLOT_BYTES;
@@ -283,12 +303,11 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
     if (group == K16_G1) {
         // the G1 kernels work in the radix-2^29 / R' domain: bring the few window/bit sums back to the
         // reference's canonical Montgomery form first (exact conversion)
+        std::vector<Xyzz9> raw(cnt);
+        memcpy(raw.data(), src, (size_t)cnt * sizeof(Xyzz9));
+        pop(); // the slot may be reused from here on
         std::vector<G1Xyzz> T(cnt);
-        for (unsigned i = 0; i < cnt; i++) {
-            Xyzz9 p9;
-            memcpy(&p9, src + (size_t)i * sizeof(Xyzz9), sizeof p9);
-            T[i] = xyzz9_to_canonical(p9);
-        }
+        for (unsigned i = 0; i < cnt; i++) T[i] = xyzz9_to_canonical(raw[i]);
         G1Xyzz r;
         if (pd.flat)
             flat_combine_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
@@ -300,10 +319,12 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
             memcpy(h_out_affine, &a, sizeof a);
         }
     } else {
+        std::vector<Xyzz<Fq2n>> raw(cnt);
+        memcpy(raw.data(), src, (size_t)cnt * sizeof(Xyzz<Fq2n>));
+        pop();
         std::vector<G2Xyzz> T(cnt);
         for (unsigned i = 0; i < cnt; i++) {
-            Xyzz<Fq2n> p9;
-            memcpy(&p9, src + (size_t)i * sizeof p9, sizeof p9);
+            const Xyzz<Fq2n>& p9 = raw[i];
             T[i] = p9.is_zero() ? G2Xyzz::zero()
                                 : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
                                          fq2n_to_canonical(p9.zzz)};
@@ -317,6 +338,41 @@ extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine
         }
     }
     return K16_OK;
+}
+
+extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
+{
+    return msm_finish_any(ctx, -1, h_out_xyzz, h_out_affine);
+}
+extern "C" int k16_msm_finish_group(k16_ctx* ctx, int group, void* h_out_xyzz, void* h_out_affine)
+{
+    if (group != K16_G1 && group != K16_G2) return K16_ERR_ARG;
+    return msm_finish_any(ctx, group, h_out_xyzz, h_out_affine);
+}
+extern "C" int k16_msm_pending(k16_ctx* ctx)
+{
+    if (!ctx) return K16_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->ring_mu);
+    return ctx->pend_count;
+}
+// Error recovery: wait for and drop every MSM still in flight, forget any bucket sort marked for reuse and go back to
+// lane 0, so that the next caller starts from a clean queue (a prover that failed half-way must not leave its MSMs behind).
+extern "C" int k16_msm_abort_all(k16_ctx* ctx)
+{
+    if (!ctx) return K16_ERR_ARG;
+    int rc = K16_OK;
+    while (k16_msm_pending(ctx) > 0) {
+        int r = msm_finish_any(ctx, -1, nullptr, nullptr);
+        if (r && !rc) rc = r;
+    }
+    ctx->reuse_sort      = false;
+    ctx->reuse_sort_lane = -1;
+    ctx->cur_lane        = 0;
+    ctx->forced_seg      = 0;
+    (void)hipSetDevice(ctx->device);
+    for (auto& L : ctx->lanes)
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+    return rc;
 }
 
 // One device call handles up to 2^24 points on the fast (LDS partition) sort.  A larger MSM on ONE GPU is the same
@@ -333,7 +389,7 @@ extern "C" int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void*
         if (rc) return rc;
         return k16_msm_finish(ctx, h_out_xyzz, h_out_affine);
     }
-    if (ctx->pend_count != 0) {
+    if (k16_msm_pending(ctx) != 0) {
         ctx->err = "k16_msm: a chunked (n > 2^24) call needs an empty MSM queue";
         return K16_ERR_ARG;
     }
@@ -358,7 +414,7 @@ extern "C" int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void*
     }
     ctx->cur_lane = saved;
     if (rc) {
-        while (ctx->pend_count) (void)k16_msm_finish(ctx, nullptr, nullptr); // drain
+        (void)k16_msm_abort_all(ctx); // drain
         return rc;
     }
     return k16_points_sum(group, parts.data(), chunks, h_out_xyzz, h_out_affine);

@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -475,10 +476,44 @@ extern "C" int k16_prover_info(const k16_prover* p, uint32_t* n_vars, uint32_t* 
     return K16_OK;
 }
 
+// K16_FAULT_INJECT="hip_after_msm" (every prove while it is set) or "hip_after_msm:<k>" (only the k-th prove of this
+// process, 1-based): the prove fails with K16_ERR_HIP after its witness MSMs have been enqueued -- the state a device
+// fault or an allocation failure in the middle of a proof leaves behind.  Test hook for the error paths
+// (tests/test_boundary.py, tests/test_gpu_parity.py); read at every call, costs one getenv.
+static bool fault_injected_now()
+{
+    static std::atomic<long> calls{0};
+    const long               k = ++calls;
+    const char*              e = getenv("K16_FAULT_INJECT");
+    if (!e || strncmp(e, "hip_after_msm", 13) != 0) return false;
+    return e[13] != ':' || atol(e + 14) == k;
+}
+
+static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
+                           char* out_json, size_t cap, float* device_ms);
+
 extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in,
                                     const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
 {
     if (!p || !h_wtns || !out_json) return K16_ERR_ARG;
+    int rc = prove_mem_inner(p, h_wtns, n_vars, r_in, s_in, out_json, cap, device_ms);
+    if (rc < 0) {
+        // Whatever failed, nothing of this proof may stay behind: MSMs already enqueued are waited for and dropped (the
+        // next prove would otherwise pop them as ITS results), the sort-reuse flags and the lane selection are reset,
+        // and the chain stream is drained.  The error text of the failure is kept.
+        k16_ctx*          ctx = p->ctx;
+        const std::string err = ctx->err;
+        (void)k16_msm_abort_all(ctx);
+        if (p->st2) (void)hipStreamSynchronize(p->st2);
+        ctx->forced_c = 0;
+        ctx->err      = err;
+    }
+    return rc;
+}
+
+static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
+                           char* out_json, size_t cap, float* device_ms)
+{
     k16_ctx* ctx = p->ctx;
     if (n_vars < p->n_vars) { // the reference does not check; reading past the buffer is not an option here
         ctx->err = "witness has fewer values than the circuit has wires";
@@ -594,6 +629,10 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
     }
     ht("A C B1 B2 enqueued");
+    if (fault_injected_now()) {
+        ctx->err = "injected fault (K16_FAULT_INJECT)";
+        return K16_ERR_HIP;
+    }
     // groth16.cpp:281-283
     ctx->cur_lane = 1;
     K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_h, 0));
@@ -618,21 +657,21 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     G1Xyzz d1_rs_neg = pneg(h_mul(d1, rs_b));
 
     ht("H enqueued + host blinding");
-    if ((rc = k16_msm_finish(ctx, &pi_a, nullptr))) return rc;
+    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_a, nullptr))) return rc;
     ht("A finished");
     pi_a          = h_madd(pi_a, p->alpha1);
     pi_a          = h_add(pi_a, d1_r);
     G1Xyzz a_s    = h_mul(pi_a, s_std);
-    if ((rc = k16_msm_finish(ctx, &pi_c, nullptr))) return rc; // enqueue order: A, C, B1, B2, H
-    if ((rc = k16_msm_finish(ctx, &pib1, nullptr))) return rc;
+    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_c, nullptr))) return rc; // enqueue order: A, C, B1, B2, H
+    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pib1, nullptr))) return rc;
     pib1          = h_madd(pib1, p->beta1);
     pib1          = h_add(pib1, d1_s);
     G1Xyzz b1_r   = h_mul(pib1, r_std);
-    if ((rc = k16_msm_finish(ctx, &pi_b, nullptr))) return rc;
+    if ((rc = k16_msm_finish_group(ctx, K16_G2, &pi_b, nullptr))) return rc;
     pi_b = h_madd(pi_b, p->beta2);
     pi_b = h_add(pi_b, d2_s);
     ht("B2 finished");
-    if ((rc = k16_msm_finish(ctx, &pih, nullptr))) return rc;
+    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pih, nullptr))) return rc;
     ht("H finished");
     K16_HIP(ctx, hipStreamWaitEvent(st, ctx->pend_ev[(ctx->pend_head + k16_ctx::PEND_SLOTS - 1) % k16_ctx::PEND_SLOTS], 0));
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
@@ -688,6 +727,7 @@ extern "C" int k16_prover_last_h(k16_prover* p, void* h_out)
 {
     if (!p || !h_out) return K16_ERR_ARG;
     k16_ctx* ctx = p->ctx;
+    K16_HIP(ctx, hipSetDevice(ctx->device));
     // after prove(), d_a holds the H scalars (standard form)
     K16_HIP(ctx, hipMemcpyAsync(h_out, p->d_a, (size_t)p->domain_size * 32, hipMemcpyDeviceToHost, ctx->stream));
     K16_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -15,10 +15,17 @@ G1, G2 = 0, 1
 OPT_PIPELINED_MSM = 1
 OPT_GRAPHS = 2
 FQ, FR = 0, 1
+FQ9, FR9, FQ2N = 2, 3, 4          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
+G1_ENG9, G2_ENG2N = 2, 3
 OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT = range(7)
 PT_ADD, PT_MADD, PT_DBL = range(3)
-AFF_BYTES = {G1: 64, G2: 128}
-XYZZ_BYTES = {G1: 128, G2: 256}
+AFF_BYTES = {G1: 64, G2: 128, G1_ENG9: 64, G2_ENG2N: 128}
+XYZZ_BYTES = {G1: 128, G2: 256, G1_ENG9: 128, G2_ENG2N: 256}
+
+
+def op_bound(op, ka=0, kb=0):
+    """K16_OP_BOUND_A / _B: operands moved up by ka / kb multiples of the modulus (radix-2^29 selectors only)."""
+    return op | (ka << 8) | (kb << 12)
 
 ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -6: "CURVE", -7: "BUFFER"}
 
@@ -27,7 +34,7 @@ SYMBOLS = [
     "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
-    "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
+    "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
@@ -72,6 +79,9 @@ def load():
     L.k16_msm_host.argtypes = [vp, i32, vp, vp, u64, vp, vp]
     L.k16_msm_enqueue.argtypes = [vp, i32, vp, vp, u64]
     L.k16_msm_finish.argtypes = [vp, vp, vp]
+    L.k16_msm_finish_group.argtypes = [vp, i32, vp, vp]
+    L.k16_msm_pending.argtypes = [vp]
+    L.k16_msm_abort_all.argtypes = [vp]
     L.k16_msm_bases_prepare.argtypes = [vp, i32, vp, u64, vp]
     L.k16_msm_enqueue_prepared.argtypes = [vp, i32, vp, vp, u64]
     L.k16_msm_fixed_base_info.argtypes = [u64, C.POINTER(u32), C.POINTER(u64)]
@@ -224,8 +234,14 @@ class Context:
     def msm_finish(self, group):
         x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
         a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
-        self._chk(self.L.k16_msm_finish(self.h, _p(x), _p(a)))
+        self._chk(self.L.k16_msm_finish_group(self.h, group, _p(x), _p(a)))   # refuses a result of the other group
         return x.tobytes(), a.tobytes()
+
+    def msm_pending(self):
+        return self.L.k16_msm_pending(self.h)
+
+    def msm_abort_all(self):
+        self._chk(self.L.k16_msm_abort_all(self.h))
 
     def msm(self, group, bases, scalars):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -259,7 +275,7 @@ class Context:
         n = a.shape[0]
         if b is not None:
             b = np.ascontiguousarray(b, dtype=np.uint64)
-        r = np.zeros((n, 4), dtype=np.uint64)
+        r = np.zeros_like(a)              # (n, 4) u64; (n, 8) for FQ2N elements
         self._chk(self.L.k16_field_op_vec(self.h, field, op, _p(a), _p(b), _p(r), n))
         return r
 

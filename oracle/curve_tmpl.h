@@ -391,9 +391,11 @@ static inline unsigned CV(window_bits)(u64 n)
 }
 
 /*
- * multiexp.cpp:183-245.  Windows are independent until the final Horner
- * combine, so the (optional) OpenMP parallelism here is over windows with a
- * private bucket array each; the arithmetic per window is the reference's.
+ * multiexp.cpp:183-245.  The reference parallelises processChunk over POINTS with one bucket array per thread
+ * (multiexp.cpp:46-71, indexed by current_thread_index()) and then packs the thread copies (packThreads, :109-130).
+ * Here the (optional) OpenMP parallelism is over (window, slice of the points) pairs, each with a private bucket
+ * array, followed by the same pack step and the reference's reduction per window -- so the port scales to any core
+ * count like the TBB loop does (nthreads = 1 is the plain serial algorithm).
  */
 static void CV(msm)(CV(pt_t)* r, const CV(aff_t)* bases, const uint8_t* scalars, u64 scalar_size, u64 n,
                     int nthreads)
@@ -409,20 +411,38 @@ static void CV(msm)(CV(pt_t)* r, const CV(aff_t)* bases, const uint8_t* scalars,
     u64 c            = CV(window_bits)(n);
     u64 nchunks      = ((scalar_size * 8 - 1) / c) + 1;
     u64 accs_per     = (u64)1 << c;
-    CV(pt_t)* chunks = (CV(pt_t)*)malloc(nchunks * sizeof(CV(pt_t)));
     if (nthreads < 1) nthreads = 1;
+    /* slices per window: enough (window, slice) tasks for every thread, each slice at least 4096 points */
+    u64 nslices = ((u64)nthreads + nchunks - 1) / nchunks;
+    if (nslices > n / 4096) nslices = n / 4096;
+    if (nslices < 1) nslices = 1;
+    CV(pt_t)* chunks = (CV(pt_t)*)malloc(nchunks * sizeof(CV(pt_t)));
+    CV(pt_t)* accs   = (CV(pt_t)*)malloc(nchunks * nslices * accs_per * sizeof(CV(pt_t)));
+    const int64_t ntasks = (int64_t)(nchunks * nslices);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (u64 w = 0; w < nchunks; w++) {
-        CV(pt_t)* accs = (CV(pt_t)*)malloc(accs_per * sizeof(CV(pt_t)));
-        for (u64 i = 0; i < accs_per; i++) CV(set_zero)(&accs[i]);
-        for (u64 i = 0; i < n; i++) {
+    for (int64_t t = 0; t < ntasks; t++) {
+        const u64 w = (u64)t / nslices, s = (u64)t % nslices;
+        CV(pt_t)* a = accs + (u64)t * accs_per;
+        for (u64 i = 0; i < accs_per; i++) CV(set_zero)(&a[i]);
+        const u64 lo = n * s / nslices, hi = n * (s + 1) / nslices;
+        for (u64 i = lo; i < hi; i++) {
             if (CV(aff_is_zero)(&bases[i])) continue;
             u64 d = CV(get_chunk)(scalars, scalar_size, c, i, w);
-            if (d) CV(madd)(&accs[d], &accs[d], &bases[i]);
+            if (d) CV(madd)(&a[d], &a[d], &bases[i]);
         }
-        CV(bucket_reduce)(&chunks[w], accs, c);
-        free(accs);
     }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t w = 0; w < (int64_t)nchunks; w++) {
+        CV(pt_t)* a0 = accs + (u64)w * nslices * accs_per;
+        /* packThreads (multiexp.cpp:109-130): bucket d of slice 0 += bucket d of every other slice */
+        for (u64 s = 1; s < nslices; s++) {
+            CV(pt_t)* as = a0 + s * accs_per;
+            for (u64 d = 1; d < accs_per; d++)
+                if (!CV(is_zero)(&as[d])) CV(add)(&a0[d], &a0[d], &as[d]);
+        }
+        CV(bucket_reduce)(&chunks[w], a0, c);
+    }
+    free(accs);
     *r = chunks[nchunks - 1];
     for (int64_t j = (int64_t)nchunks - 2; j >= 0; j--) {
         for (u64 k = 0; k < c; k++) CV(dbl)(r, r);

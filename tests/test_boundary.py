@@ -137,3 +137,25 @@ def test_fullprover_pool_concurrent_callers(tmp_path, toy_paths):
                          env=dict(os.environ, K16_DEVICES="0,99"))
     assert bad.stdout.splitlines()[0] == "state=1"
     assert "no usable" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_fullprover_device_fault_is_not_the_callers_fault(tmp_path, toy_paths):
+    """A HIP failure inside prove() (injected: K16_FAULT_INJECT) is reported as PROVER_NOT_READY -- the class the service
+    retries -- not INVALID_INPUT, the slot is rebuilt in a fresh context before it is handed out again, and the proofs
+    after it are good (RS/fullprover.cpp:91-125 maps only its own exception classes; a GPU build adds this one)."""
+    import json
+    import bn254_pairing as bp
+    zkey, wtns, vk = toy_paths
+    exe = build_harness(tmp_path)
+    env = dict(os.environ, K16_FAULT_INJECT="hip_after_msm:2")
+    out = subprocess.run([exe, zkey, wtns, "4"], capture_output=True, text=True, timeout=300, env=env)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr
+    assert lines[1].startswith("type=0 error=0")
+    assert lines[3].startswith("type=1 error=1"), lines           # ERROR / PROVER_NOT_READY
+    assert lines[4] == ""
+    for k in (5, 7):
+        assert lines[k].startswith("type=0 error=0"), lines
+        assert json.loads(lines[k + 1])["protocol"] == "groth16"
+        assert bp.verify_json(vk, lines[k + 1], [2])

@@ -527,3 +527,198 @@ def test_msm_g1_above_2p24_is_chunked(ctx):
     assert ol.pt_eq(0, x, want)
     d_b.free()
     d_s.free()
+
+
+# ---------------------------------------------------------------- the arithmetic the HOT kernels run (radix-2^29 field, Eng9 / Eng2n)
+@pytest.mark.parametrize("field,sel", [(0, "FQ9"), (1, "FR9")])
+def test_field_ops_hot_path_representation(ctx, field, sel):
+    """k16_field_op_vec with the K16_FQ9 / K16_FR9 selectors: the same canonical inputs and outputs as test_field_ops, but
+    the operation runs on the unsaturated radix-2^29 field the MSM / NTT kernels use (fmul9, fsqr9, fadd9, fsub9 and the
+    conversions); operands are also moved up to the bounds the point formulas document (value + k*p)."""
+    import k16
+    p = pm.Q if field == 0 else pm.R
+    rng = pm.SplitMix64(177 + field)
+    n = 4096
+    a, b = rand_fe_array(rng, p, n), rand_fe_array(rng, p, n)
+    b[:8] = a[:8][::-1]
+    selv = getattr(k16, sel)
+    for op in range(7):
+        want = ol.field_op_vec(field, op, a, b)
+        # (ka, kb): multiples of the modulus added to the operands; products must stay within (2+ka)(2+kb) <= 128
+        for ka, kb in ((0, 0), (6, 0), (0, 6), (6, 6), (2, 5)):
+            got = ctx.field_op_vec(selv, k16.op_bound(op, ka, kb), a, b)
+            assert np.array_equal(got, want), (sel, op, ka, kb)
+
+
+def test_fq2_ops_hot_path_representation(ctx):
+    """Fq2n (Fq2 over the radix-2^29 field: fmul9_sum2 products, fred9 partial reductions) against the oracle's Fq2
+    (f2field.cpp:94-176), including the reference's own KAT (2,2)*(3,3) = (0,12) (alt_bn128_test.cpp:12-30)."""
+    import k16
+    rng = pm.SplitMix64(909)
+    n = 2048
+    a = np.concatenate([rand_fe_array(rng, pm.Q, n), rand_fe_array(rng, pm.Q, n)], axis=1)   # (n, 8): a | b
+    b = np.concatenate([rand_fe_array(rng, pm.Q, n), rand_fe_array(rng, pm.Q, n)], axis=1)
+    mont = lambda v: np.frombuffer(pm.limbs(v * pm.MONT % pm.Q), dtype=np.uint64)
+    a[0] = np.concatenate([mont(2), mont(2)])
+    b[0] = np.concatenate([mont(3), mont(3)])
+    a[1], b[1] = 0, b[5]                   # 0 * y, and x - x, x + (-x) below
+    b[2] = a[2]
+    for op in (k16.OP_ADD, k16.OP_SUB, k16.OP_NEG, k16.OP_MUL, k16.OP_SQR):
+        got = ctx.field_op_vec(k16.FQ2N, op, a, b)
+        for i in range(n):
+            want = ol.fq2_op(op, a[i].tobytes(), b[i].tobytes())
+            assert got[i].tobytes() == want, (op, i)
+    prod = ctx.field_op_vec(k16.FQ2N, k16.OP_MUL, a[:1], b[:1])[0]
+    assert prod[:4].tobytes() == bytes(32) and prod[4:].tobytes() == mont(12).tobytes()
+
+
+@pytest.mark.parametrize("sel,group", [("G1_ENG9", 0), ("G2_ENG2N", 1)])
+def test_point_ops_hot_path_formulas(ctx, sel, group):
+    """padd9 / padd_mixed9 / pdbl9 (G1) and the Fq2n instantiation of the XYZZ templates (G2) -- the formulas the bucket
+    accumulation, fold and reduction kernels execute -- against the oracle, XYZZ representation for every branch of
+    curve.cpp:91-250 (inf + P, P + inf, P + P -> dbl, P + (-P) -> inf, (0,0) rows), with G1 operands also at the documented
+    bounds X < 8p, Y < 4p."""
+    import k16
+    selv = getattr(k16, sel)
+    n = 64
+    aff = ol.gen_points(group, 3, n)
+    xb = k16.XYZZ_BYTES[group]
+    g = ol.generator(group)
+    proj = np.zeros((n, xb), dtype=np.uint8)
+    other = np.zeros((n, xb), dtype=np.uint8)
+    for i in range(n):
+        proj[i] = np.frombuffer(ol.mul_scalar(group, g, pm.limbs(i + 4)), dtype=np.uint8)
+        other[i] = np.frombuffer(ol.mul_scalar(group, g, pm.limbs(1000 + 7 * i)), dtype=np.uint8)
+    inf = np.frombuffer(ol.mul_scalar(group, g, pm.limbs(0)), dtype=np.uint8)
+    p1, p2x, p2a = other.copy(), proj.copy(), aff.copy()
+    p1[0] = inf
+    p2x[1] = inf
+    p2a[1] = 0
+    p1[2] = proj[2]
+    p1[3] = np.frombuffer(ol.pt_op(group, ol.PT_NEG, bytes(proj[3])), dtype=np.uint8)
+    p1[4] = inf
+    p2x[4] = inf
+    p2a[4] = 0
+    omap = {k16.PT_ADD: ol.PT_ADD, k16.PT_MADD: ol.PT_MADD, k16.PT_DBL: ol.PT_DBL}
+    for op, p2 in ((k16.PT_ADD, p2x), (k16.PT_MADD, p2a), (k16.PT_DBL, None)):
+        want = [ol.pt_op(group, omap[op], bytes(p1[i]), bytes(p2[i]) if p2 is not None else None) for i in range(n)]
+        bounds = [(0, 0)]
+        if group == 0:
+            bounds += [(2, 0), (1, 0)] + ([(2, 2), (0, 2)] if op == k16.PT_ADD else [])
+        for ka, kb in bounds:
+            got = ctx.point_op_vec(selv, k16.op_bound(op, ka, kb), p1, p2)
+            for i in range(n):
+                if i == 3 and op != k16.PT_DBL:
+                    # P + (-P): zz3 = 0 by the general formula; x3, y3 are whatever it leaves (equal mod p)
+                    assert ol.pt_eq(group, bytes(got[i]), want[i]) and bytes(got[i][xb // 2:]) == bytes(xb // 2), (sel, op, i)
+                assert bytes(got[i]) == want[i], (sel, op, ka, kb, i)
+
+
+# ---------------------------------------------------------------- full-size parity (BASELINE config 3 at scale 1.0)
+def test_keyless_shape_proof_full_size_bit_exact(ctx, tmp_path):
+    """The Keyless SHAPE at its stated size -- nVars 1,343,588, nPublic 1, N = 2^21, 8.3 M coefficients, B1/B2 half (0,0),
+    witness 90 % bits / 8 % bytes / 2 % full width -- on a synthetic key: proof JSON and all 2^21 H scalars byte-equal to
+    the CPU oracle's (RS/groth16.cpp:41-360).  This is the configuration whose code paths no smaller test reaches: NTT
+    passes 1-10 / 11-16 / 17-21, the c = 20 fixed-base H MSM with 13 window tables, a ~600 k-point witness bucket
+    through the giant fold, B2 with 1.34 M G2 points."""
+    import bench
+    import k16
+    n_vars, N, n_coefs = bench.KEYLESS["n_vars"], bench.KEYLESS["domain"], bench.KEYLESS["n_coefs"]
+    zk = str(tmp_path / "keyless_shape.zkey")
+    wt = str(tmp_path / "keyless_shape.wtns")
+    with open(zk, "wb") as f:
+        f.write(bench.synth_zkey_bytes(ctx, k16, n_vars, 1, N, n_coefs))
+    w = bench.synth_witness(n_vars, 100)
+    bench.write_wtns(wt, w)
+    r, s = pm.limbs(pm.SplitMix64(177).below(pm.R)), pm.limbs(pm.SplitMix64(178).below(pm.R))
+    p = k16.Prover(ctx, zk)
+    assert p.info() == dict(n_vars=n_vars, n_public=1, domain_size=N, n_coefs=n_coefs)
+    got = p.prove_mem(w, r, s)
+    h_gpu = p.last_h()
+    got_file = p.prove_file(wt, r, s)
+    want, h_ref = ol.prove_files(zk, wt, r, s, nthreads=os.cpu_count() or 8, want_h=True)
+    assert np.array_equal(h_gpu, h_ref)
+    assert got == want
+    assert got_file == want
+    # and a second witness on the warm prover (workspaces, sort reuse across proofs)
+    w2 = bench.synth_witness(n_vars, 101)
+    bench.write_wtns(wt, w2)
+    assert p.prove_mem(w2, r, s) == ol.prove_files(zk, wt, r, s, nthreads=os.cpu_count() or 8)
+    p.close()
+
+
+def test_ntt_forward_and_inverse_2p21_vs_oracle(ctx):
+    """The Keyless domain, both directions, compared with the oracle directly (not a round trip): FFT::fft / ::ifft
+    (RS/fft.cpp:192-246) with the 2^22 root table the prover builds."""
+    n = 1 << 21
+    rs = np.random.RandomState(13)
+    a = rs.randint(0, 2 ** 63, size=(n, 4)).astype(np.uint64)
+    a[:, 3] &= (1 << 60) - 1     # < r
+    for inverse in (False, True):
+        got = ctx.ntt(a, max_domain=2 * n, inverse=inverse)
+        want = ol.ntt(a, max_domain=2 * n, inverse=inverse)
+        assert np.array_equal(got, want), inverse
+
+
+@pytest.mark.parametrize("kind", ["uniform", "witness"])
+def test_msm_g2_2p20_vs_oracle(ctx, kind):
+    """G2 at the size of the prover's B2 MSM (RS/groth16.cpp:100-102), half of the rows (0,0) as in a real key."""
+    n = 1 << 20
+    bases = ol.gen_points(1, 7, n)
+    rs = np.random.RandomState(5)
+    bases[rs.rand(n) < 0.5] = 0
+    scalars = np_scalars(61, n, kind)
+    if kind == "witness":
+        ctx.set_window_bits(13)          # what the prover uses for its witness MSMs
+    try:
+        _check_msm(ctx, 1, bases, scalars, threads=os.cpu_count() or 8)
+    finally:
+        ctx.set_window_bits(0)
+
+
+def test_msm_more_giant_buckets_than_the_giant_list_holds(ctx, monkeypatch):
+    """300 buckets with > 2048 segments each (K16_SEG=1: one entry per segment): the giant list holds 256, the rest must
+    be folded through the medium path (k_classify) -- before the fix they kept only their first partial."""
+    vals, copies = 300, 2100
+    n = vals * copies
+    bases = ol.gen_points(0, 0, 4096)[np.arange(n) % 4096]
+    scalars = np.zeros((n, 32), dtype=np.uint8)
+    v = (np.arange(n) % vals + 1).astype(np.uint16)
+    scalars[:, :2] = v.view(np.uint8).reshape(n, 2)
+    _, want = ol.msm(0, bases, scalars, nthreads=os.cpu_count() or 8)
+    monkeypatch.setenv("K16_SEG", "1")
+    _, got = ctx.msm(0, bases, scalars)
+    assert got == want
+
+
+def test_prover_failure_leaves_no_stale_msms(ctx, tmp_path, monkeypatch):
+    """A prove that fails after its witness MSMs were enqueued (K16_FAULT_INJECT) must drain them: the queue is empty
+    afterwards and the next proof on the same prover is the right one (before the fix it was built from the failed
+    proof's MSMs, or overflowed a G1 buffer with a G2 result)."""
+    import k16
+    import zkey_builder as zb
+    zk, wt = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    zb.build_zkey(zk, 3000, 2, 4096, 9000, seed=21)
+    w = zb.build_wtns(wt, 3000, seed=22)
+    r, s = pm.limbs(5), pm.limbs(6)
+    want = ol.prove_files(zk, wt, r, s, nthreads=4)
+    p = k16.Prover(ctx, zk)
+    assert p.prove_mem(w, r, s) == want
+    monkeypatch.setenv("K16_FAULT_INJECT", "hip_after_msm")
+    with pytest.raises(k16.K16Error) as ei:
+        p.prove_mem(w, r, s)
+    assert ei.value.rc == -2 and "injected" in str(ei.value)
+    monkeypatch.delenv("K16_FAULT_INJECT")
+    assert ctx.msm_pending() == 0
+    assert p.prove_mem(w, r, s) == want
+    # a result of the wrong group is refused, not copied
+    n = 64
+    d_b, d_s = ctx.to_device(ol.gen_points(1, 0, n)), ctx.to_device(np_scalars(5, n, "uniform"))
+    ctx.msm_enqueue(k16.G2, d_b, d_s, n)
+    with pytest.raises(k16.K16Error):
+        ctx.msm_finish(k16.G1)
+    assert ctx.msm_pending() == 1
+    assert ctx.msm_finish(k16.G2)[1] == ol.msm(1, ol.gen_points(1, 0, n), np_scalars(5, n, "uniform"))[1]
+    d_b.free()
+    d_s.free()
+    p.close()
