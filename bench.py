@@ -526,6 +526,7 @@ def main():
     d_bases.free()
     d_scalars.free()
     proof = None
+    ctx.set_option(k16.OPT_PIPELINED_MSM, 0)   # the prover wants the latency-tuned defaults (include/k16.h)
     if args.proofs > 0:
         proof = proof_leg(ctx, k16, torch, dist, rank, world, args.proofs,
                           check_with_oracle=(world == 1 and not args.no_cpu_baseline), scale=args.proof_scale)

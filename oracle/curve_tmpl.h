@@ -431,17 +431,24 @@ static void CV(msm)(CV(pt_t)* r, const CV(aff_t)* bases, const uint8_t* scalars,
             if (d) CV(madd)(&a[d], &a[d], &bases[i]);
         }
     }
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (int64_t w = 0; w < (int64_t)nchunks; w++) {
-        CV(pt_t)* a0 = accs + (u64)w * nslices * accs_per;
-        /* packThreads (multiexp.cpp:109-130): bucket d of slice 0 += bucket d of every other slice */
-        for (u64 s = 1; s < nslices; s++) {
-            CV(pt_t)* as = a0 + s * accs_per;
-            for (u64 d = 1; d < accs_per; d++)
-                if (!CV(is_zero)(&as[d])) CV(add)(&a0[d], &a0[d], &as[d]);
-        }
-        CV(bucket_reduce)(&chunks[w], a0, c);
+    /* packThreads (multiexp.cpp:109-130): bucket d of slice 0 += bucket d of every other slice; like the reference's
+     * parallel_for over buckets, in blocks of 1024 buckets per task */
+    if (nslices > 1) {
+        const int64_t nblk = (int64_t)((accs_per + 1023) / 1024);
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(nthreads)
+        for (int64_t w = 0; w < (int64_t)nchunks; w++)
+            for (int64_t blk = 0; blk < nblk; blk++) {
+                CV(pt_t)* a0 = accs + (u64)w * nslices * accs_per;
+                u64 d0 = (u64)blk * 1024, d1 = d0 + 1024 < accs_per ? d0 + 1024 : accs_per;
+                for (u64 s = 1; s < nslices; s++) {
+                    CV(pt_t)* as = a0 + s * accs_per;
+                    for (u64 d = d0 ? d0 : 1; d < d1; d++)
+                        if (!CV(is_zero)(&as[d])) CV(add)(&a0[d], &a0[d], &as[d]);
+                }
+            }
     }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t w = 0; w < (int64_t)nchunks; w++) CV(bucket_reduce)(&chunks[w], accs + (u64)w * nslices * accs_per, c);
     free(accs);
     *r = chunks[nchunks - 1];
     for (int64_t j = (int64_t)nchunks - 2; j >= 0; j--) {
