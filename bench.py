@@ -420,6 +420,8 @@ def main():
     chunked = n > (1 << 24)   # one device pass takes 2^24 points; above that k16_msm runs chunks on two lanes and folds them
 
     import threading
+    if os.environ.get("K16_BENCH_SWITCH"):
+        sys.setswitchinterval(float(os.environ["K16_BENCH_SWITCH"]))
 
     def run(steps):
         """steps complete MSMs, up to `depth` of them in flight.  The launches of MSM k+depth-1 are issued by a second host
@@ -446,7 +448,10 @@ def main():
                 try:
                     for _ in range(steps):
                         room.acquire()
+                        te = time.perf_counter()
                         enqueue()
+                        if step_times is not None:
+                            enq_times.append((time.perf_counter() - te) * 1e3)
                         ready.release()
                 except BaseException as e:   # surface in the main thread instead of deadlocking it
                     failed.append(e)
@@ -460,6 +465,8 @@ def main():
                 if failed:
                     break
                 res = finish()
+                if step_times is not None:
+                    step_times.append(time.perf_counter())
                 room.release()
             th.join()
             if failed:
@@ -468,6 +475,15 @@ def main():
             res, _ = sharding.exchange_finish(pending_x.pop(0))
         return res
 
+    step_times = [] if os.environ.get("K16_BENCH_TRACE") else None   # diagnostics: completion time of every step
+    enq_times = []
+    # Device warm-up, part of the set-up (reported as "prewarm_steps"; the W warm-up steps and the K timed steps follow
+    # unchanged).  A fresh process needs ~40 MSMs before it runs at its steady rate: every lane's first MSM allocates its
+    # workspaces (5-12 ms each), and the GPU's clocks ramp up over the first ~30 ms of load (per-step time 1.83 -> 1.65 ms,
+    # gpurun_out traces in profiles/r02/); with W = 5 the driver's 20 timed steps would measure mostly that ramp.
+    prewarm = int(os.environ.get("K16_BENCH_PREWARM", "48"))
+    if prewarm:
+        run(prewarm)
     if args.warmup:
         run(args.warmup)
 
@@ -482,10 +498,16 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if step_times:
+        ts = step_times[-args.steps:]
+        print("[bench trace] per-step ms: " + " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + ts[:-1], ts)),
+              file=sys.stderr, flush=True)
+        print("[bench trace] enqueue ms (all steps incl. warm-up): " + " ".join("%.2f" % v for v in enq_times),
+              file=sys.stderr, flush=True)
     launches, acc_ms = ctx.stats_get("msm_accumulate")
     # host side of one step (C entry points only): launches, waiting for the GPU, conversion + Horner
     host_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
-               for k in ("host_enqueue", "host_finish_wait", "host_finish_combine")}
+               for k in ("host_enqueue", "host_finish_wait", "host_finish_combine", "host_enqueue_max")}
     # the same kernel without a neighbour on the GPU (one MSM at a time), for reference next to the live figure; this
     # untimed pass also times the other stages
     ctx.stats_enable(1)
@@ -557,6 +579,7 @@ def main():
             "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_steps": prewarm,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",

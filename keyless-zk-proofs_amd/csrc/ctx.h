@@ -62,13 +62,18 @@ struct k16_ctx {
         uint64_t                       graphs_gen = 0; // workspace generation the cached graphs were captured for
         hipEvent_t  sort_done = nullptr; // recorded on `stream` after every bucket sort (cross-lane reuse waits on it)
         hipEvent_t  acc_done  = nullptr; // recorded after every bucket accumulation (see serialize_acc)
+        hipEvent_t  lvl1_done = nullptr; // ... after the first level of the weighted bucket sum, and after the whole
+        hipEvent_t  tail_done = nullptr; //     reduction (see acc_fence_mode)
         const void* sorted_scalars = nullptr;
         uint64_t    sorted_n = 0;
         unsigned    sorted_c = 0;
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
-    void* pinned = nullptr; // small pinned host staging buffer
+    void* pinned = nullptr;     // small pinned host staging buffer (coherent, mapped into the device's address space)
+    void* pinned_dev = nullptr; // its device-side address: the last kernel of an MSM writes its <= 240 partial sums straight
+                                // into the staging slot (a hipMemcpyAsync D2H was observed to BLOCK the enqueuing thread for
+                                // 7-13 ms a few times per process while the runtime set up its copy path)
     size_t pinned_bytes = 0;
 
     // state of the MSM currently enqueued (k16_msm_enqueue -> k16_msm_finish)
@@ -118,6 +123,19 @@ struct k16_ctx {
     // 16 (4) does 12 % less reduction work with chains twice as long -- +5 % for pipelined MSMs, +4 % latency for one
     unsigned    wsum_mlog_cap = 3;
     hipEvent_t  last_acc_done = nullptr;
+    // the same fence for the bucket sorts (K16_OPT_PIPELINED_MSM): when several MSMs are enqueued at once -- the start of a
+    // pipelined run -- their sorts would otherwise share the GPU and the FIRST accumulation could only start when all of
+    // them are done; one behind the other, the first MSM's accumulation starts after one sort and the later sorts run
+    // under it
+    // what a lane's accumulation waits for when serialize_acc is on: 0 the previous MSM's accumulation, 1 its first
+    // weighted-sum level (the previous tail's fold + level 1 run alone, its bit sums beside this accumulation), 2 its whole
+    // reduction.  A chip-filling accumulation starves every kernel of the other lanes that starts beside it (kernel traces:
+    // a fold launched next to an accumulation ends when the accumulation ends), so with mode 0 the tails of ALL queued MSMs
+    // wait for ALL queued accumulations.
+    int         acc_fence_mode = 0;
+    hipEvent_t  last_lvl1_done = nullptr, last_tail_done = nullptr;
+
+    hipEvent_t  last_sort_done = nullptr;
     // Unused dynamic LDS requested for the bucket accumulation, to cap ITS occupancy (K16_ACC_LDS, bytes per 128-thread
     // workgroup: 36864 -> 4 workgroups = 2 waves/SIMD per CU instead of the 3 its 159 VGPRs allow).  The registers a
     // third wave would take stay free for the other lanes' sort / fold / reduction kernels, which otherwise wait for a

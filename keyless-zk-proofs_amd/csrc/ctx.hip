@@ -36,10 +36,13 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     for (int i = 0; i < k16_ctx::N_LANES; i++)
         lanes_ok = lanes_ok && (i > 0 || hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess) &&
                    hipEventCreateWithFlags(&c->lanes[i].sort_done, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&c->lanes[i].acc_done, hipEventDisableTiming) == hipSuccess;
+                   hipEventCreateWithFlags(&c->lanes[i].acc_done, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&c->lanes[i].lvl1_done, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&c->lanes[i].tail_done, hipEventDisableTiming) == hipSuccess;
     if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
     if (const char* e = getenv("K16_WSUM_MLOG_CAP")) c->wsum_mlog_cap = (unsigned)atoi(e);
     if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
+    if (const char* e = getenv("K16_ACC_FENCE")) c->acc_fence_mode = atoi(e);
     if (const char* e = getenv("K16_ACC_LDS")) c->acc_lds_bytes = (unsigned)std::min(65536, std::max(0, atoi(e)));
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
@@ -48,7 +51,8 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
         return K16_ERR_NO_DEVICE;
     }
     c->pinned_bytes = k16_ctx::PEND_SLOTS * k16_ctx::SLOT_BYTES + 65536; // + debug area
-    if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0) != hipSuccess) {
         delete c;
         return K16_ERR_NO_DEVICE;
     }
@@ -89,6 +93,8 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (L.sort_done) (void)hipEventDestroy(L.sort_done);
         if (L.acc_done) (void)hipEventDestroy(L.acc_done);
+        if (L.lvl1_done) (void)hipEventDestroy(L.lvl1_done);
+        if (L.tail_done) (void)hipEventDestroy(L.tail_done);
         if (L.stream && (&L == &c->lanes[0] || L.stream != c->lanes[0].stream)) (void)hipStreamDestroy(L.stream);
     }
     delete c;

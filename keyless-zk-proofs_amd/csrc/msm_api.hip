@@ -184,9 +184,13 @@ struct HostTimer {
     {
         if (!c->stats_on) return;
         std::lock_guard<std::mutex> lk(c->ring_mu);
-        auto& st = c->stats[name];
+        auto&        st = c->stats[name];
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         st.launches++;
-        st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        st.total_ms += ms;
+        auto& mx = c->stats[std::string(name) + "_max"]; // the slowest call since the last reset (total_ms holds it)
+        mx.launches = 1;
+        if (ms > mx.total_ms) mx.total_ms = ms;
     }
 };
 } // namespace
