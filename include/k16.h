@@ -179,6 +179,27 @@ int  k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, co
 /* debugging / parity: H scalars of the last proof (domain_size x 32 B, standard form) */
 int  k16_prover_last_h(k16_prover* p, void* h_out);
 
+/* ---- batched Groth16 verification ----
+ * Replaces the CPU check the service runs on every proof before it is released
+ * (prover-service/src/request_handler/prover_handler.rs:329-336: Groth16Proof::verify_proof(public_inputs_hash, &pvk), i.e.
+ * ark-groth16 0.4.0 prepare_inputs + verify_proof_with_prepared_inputs over ark-ec 0.4.2 / ark-bn254 0.4.0 -- third-party
+ * crates, Cargo.lock:501-639; types.rs:141-196 prepared_vk builds the key from the decimal strings of the vkey file):
+ *     e(A, B) * e(vk_x, -gamma) * e(C, -delta) == e(alpha, beta),     vk_x = IC[0] + sum_i x_i * IC[i + 1]
+ * Points are affine, Montgomery form, little-endian -- the zkey's own point format: G1 64 B, G2 128 B.
+ * k16_vk_create uploads the key and computes e(alpha, beta) once (PreparedVerifyingKey::alpha_g1_beta_g2).
+ * k16_verify_batch: h_proofs = n x 256 B (A | B | C), h_inputs = n x (n_ic - 1) x 32 B standard-form integers (any 256-bit
+ * value; they act modulo r, as Fr::from_le_bytes_mod_order), out_ok[i] = 1 accept / 0 reject.  3n Miller loops and n final
+ * exponentiations, one GPU lane each: a throughput path for batches (BASELINE config 4 releases 64 proofs per wave). */
+typedef struct k16_vk k16_vk;
+int  k16_vk_create(k16_ctx* ctx, const void* alpha1_g1, const void* beta2_g2, const void* gamma2_g2, const void* delta2_g2,
+                   const void* ic_g1, uint32_t n_ic, k16_vk** out);
+void k16_vk_destroy(k16_vk* vk);
+int  k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, const void* h_inputs, uint64_t n,
+                      uint8_t* h_out_ok);
+/* parity tests: out[i] = e(P_i, Q_i) exactly as ark-ec's Bn::pairing gives it, 12 x 32 B per value (Fq12 = Fq6[w]/(w^2 - v),
+ * Fq6 = Fq2[v]/(v^3 - 9 - u): c0.c0.a, c0.c0.b, c0.c1.a, ...), Montgomery form */
+int  k16_pairing_vec(k16_ctx* ctx, const void* h_g1, const void* h_g2, uint64_t n, void* h_out_gt);
+
 #ifdef __cplusplus
 }
 #endif

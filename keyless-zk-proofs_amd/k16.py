@@ -38,6 +38,7 @@ SYMBOLS = [
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
+    "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_pairing_vec",
 ]
 
 _lib = None
@@ -103,6 +104,11 @@ def load():
     L.k16_prover_prove_file.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
     L.k16_prover_prove_mem.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
     L.k16_prover_last_h.argtypes = [vp, vp]
+    L.k16_vk_create.argtypes = [vp, vp, vp, vp, vp, vp, u32, C.POINTER(vp)]
+    L.k16_vk_destroy.argtypes = [vp]
+    L.k16_vk_destroy.restype = None
+    L.k16_verify_batch.argtypes = [vp, vp, vp, vp, u64, vp]
+    L.k16_pairing_vec.argtypes = [vp, vp, vp, u64, vp]
     _lib = L
     return L
 
@@ -351,3 +357,46 @@ class Prover:
         if self.h:
             self.ctx.L.k16_prover_destroy(self.h)
             self.h = None
+
+
+class VerifyingKey:
+    """Groth16 verifying key resident on the GPU (k16_vk_create) + batched verification (k16_verify_batch): the mirror of
+    the service's prepared_vk / verify_proof pair (prover-service/src/request_handler/types.rs:141-196,
+    prover_handler.rs:329-336).  vk: dict(alpha1, beta2, gamma2, delta2, ic=[...]) of affine Montgomery bytes."""
+
+    def __init__(self, ctx, vk):
+        self.ctx, self.n_ic = ctx, len(vk["ic"])
+        h = C.c_void_p()
+        b = lambda x: np.frombuffer(bytes(x), dtype=np.uint8).copy()
+        ic = b(b"".join(vk["ic"]))
+        ctx._chk(ctx.L.k16_vk_create(ctx.h, _p(b(vk["alpha1"])), _p(b(vk["beta2"])), _p(b(vk["gamma2"])), _p(b(vk["delta2"])),
+                                     _p(ic), self.n_ic, C.byref(h)))
+        self.h = h
+
+    def verify_batch(self, proofs, inputs):
+        """proofs: list of 256-byte A | B | C; inputs: per proof a list of n_ic - 1 ints.  Returns a list of bools."""
+        n = len(proofs)
+        if n == 0:
+            return []
+        pr = np.frombuffer(b"".join(bytes(p) for p in proofs), dtype=np.uint8).copy()
+        assert pr.size == 256 * n
+        inp = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for row in inputs for x in row), dtype=np.uint8).copy()
+        assert inp.size == n * (self.n_ic - 1) * 32
+        ok = np.zeros(n, dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.k16_verify_batch(self.ctx.h, self.h, _p(pr), _p(inp) if inp.size else None, n, _p(ok)))
+        return [bool(v) for v in ok]
+
+    def close(self):
+        if self.h:
+            self.ctx.L.k16_vk_destroy(self.h)
+            self.h = None
+
+
+def pairing_vec(ctx, g1, g2):
+    """e(P_i, Q_i) for affine Montgomery G1 (n, 64) / G2 (n, 128) arrays -> (n, 384) uint8 (k16_pairing_vec)."""
+    g1 = np.ascontiguousarray(g1, dtype=np.uint8)
+    g2 = np.ascontiguousarray(g2, dtype=np.uint8)
+    n = g1.shape[0]
+    out = np.zeros((n, 384), dtype=np.uint8)
+    ctx._chk(ctx.L.k16_pairing_vec(ctx.h, _p(g1), _p(g2), n, _p(out)))
+    return out

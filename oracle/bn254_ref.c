@@ -814,6 +814,89 @@ void ora_msm(int group, const void* bases_aff, const uint8_t* scalars, u64 scala
     }
 }
 
+/* ---------------------------------------------------------------- pairing / Groth16 verification (pairing_ref.h) */
+#include "pairing_ref.h"
+
+/* Miller loop value (before the final exponentiation): 12 x 32 B, Fq12 as c0.c0.a, c0.c0.b, c0.c1.a, ... Montgomery */
+void ora_miller(const void* g1_aff, const void* g2_aff, void* out_f)
+{
+    g1_aff_t p;
+    g2_aff_t q;
+    memcpy(&p, g1_aff, sizeof p);
+    memcpy(&q, g2_aff, sizeof q);
+    fq12_t f;
+    pr_miller(&f, &p, &q);
+    memcpy(out_f, &f, sizeof f);
+}
+/* e(P, Q) as ark-ec 0.4.2 Bn::pairing computes it (final_exponentiation of the Miller loop) */
+int ora_pairing(const void* g1_aff, const void* g2_aff, void* out_gt)
+{
+    fq12_t f, e;
+    ora_miller(g1_aff, g2_aff, &f);
+    if (pr_final_exp(&e, &f)) return ORA_ERR_FORMAT;
+    memcpy(out_gt, &e, sizeof e);
+    return 0;
+}
+int ora_final_exp(const void* f_in, void* out_gt)
+{
+    fq12_t f, e;
+    memcpy(&f, f_in, sizeof f);
+    if (pr_final_exp(&e, &f)) return ORA_ERR_FORMAT;
+    memcpy(out_gt, &e, sizeof e);
+    return 0;
+}
+void ora_gt_mul(const void* a, const void* b, void* out)
+{
+    pr_init();
+    fq12_t x, y, z;
+    memcpy(&x, a, sizeof x);
+    memcpy(&y, b, sizeof y);
+    fq12_mul(&z, &x, &y);
+    memcpy(out, &z, sizeof z);
+}
+/* ark-groth16 0.4.0 verifier.rs: prepare_inputs + verify_proof_with_prepared_inputs.
+ * vk points affine Montgomery (zkey / vkey formats converted by the caller), ic: n_ic G1 points, proof: A | B | C
+ * (64 + 128 + 64 B), inputs: (n_ic - 1) x 32 B standard form.  Returns 1 accept, 0 reject, < 0 malformed. */
+int ora_groth16_verify(const void* alpha1, const void* beta2, const void* gamma2, const void* delta2, const void* ic,
+                       uint32_t n_ic, const void* proof, const uint8_t* inputs)
+{
+    if (n_ic < 1) return ORA_ERR_FORMAT;
+    g1_aff_t a, c, al;
+    g2_aff_t b, be, ga, de;
+    memcpy(&al, alpha1, sizeof al);
+    memcpy(&be, beta2, sizeof be);
+    memcpy(&ga, gamma2, sizeof ga);
+    memcpy(&de, delta2, sizeof de);
+    memcpy(&a, proof, 64);
+    memcpy(&b, (const uint8_t*)proof + 64, 128);
+    memcpy(&c, (const uint8_t*)proof + 192, 64);
+    const g1_aff_t* icp = (const g1_aff_t*)ic;
+    /* prepare_inputs: g_ic = IC[0] + sum_i x_i * IC[i + 1] */
+    g1_pt_t acc;
+    g1_set_zero(&acc);
+    g1_madd(&acc, &acc, &icp[0]);
+    for (uint32_t i = 1; i < n_ic; i++) {
+        g1_pt_t t;
+        g1_mul_scalar_aff(&t, &icp[i], inputs + (size_t)(i - 1) * 32, 32);
+        g1_add(&acc, &acc, &t);
+    }
+    g1_aff_t vkx;
+    g1_to_aff(&vkx, &acc);
+    /* pvk.gamma_g2_neg_pc / delta_g2_neg_pc: the NEGATED G2 points; alpha_g1_beta_g2 = e(alpha, beta) */
+    fq2_neg(&ga.y, &ga.y);
+    fq2_neg(&de.y, &de.y);
+    fq12_t f0, f1, f2, f, test, want;
+    pr_miller(&f0, &a, &b);
+    pr_miller(&f1, &vkx, &ga);
+    pr_miller(&f2, &c, &de);
+    fq12_mul(&f, &f0, &f1);
+    fq12_mul(&f, &f, &f2);
+    if (pr_final_exp(&test, &f)) return 0;
+    pr_miller(&f0, &al, &be);
+    if (pr_final_exp(&want, &f0)) return 0;
+    return fq12_eq(&test, &want) ? 1 : 0;
+}
+
 /* FFT<Fr>(max_domain).fft / .ifft on n Montgomery elements in place */
 int ora_ntt(u64* a, u64 n, u64 max_domain, int inverse)
 {

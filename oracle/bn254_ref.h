@@ -34,6 +34,14 @@ void ora_gen_points(int group, uint64_t start, uint64_t n, void* out_aff);
 void ora_msm(int group, const void* bases_aff, const uint8_t* scalars, uint64_t scalar_size, uint64_t n, int nthreads,
              void* out_xyzz, void* out_aff);
 
+/* pairing / Groth16 verification (oracle/pairing_ref.h): Fq12 values are 12 x 32 B (c0.c0.a, c0.c0.b, c0.c1.a, ...), Montgomery */
+void ora_miller(const void* g1_aff, const void* g2_aff, void* out_f);
+int  ora_pairing(const void* g1_aff, const void* g2_aff, void* out_gt);
+int  ora_final_exp(const void* f_in, void* out_gt);
+void ora_gt_mul(const void* a, const void* b, void* out);
+int  ora_groth16_verify(const void* alpha1, const void* beta2, const void* gamma2, const void* delta2, const void* ic,
+                        uint32_t n_ic, const void* proof, const uint8_t* inputs);
+
 int ora_ntt(uint64_t* a, uint64_t n, uint64_t max_domain, int inverse);
 int ora_ntt_root(uint64_t max_domain, unsigned domain_pow, uint64_t idx, uint64_t* out);
 

@@ -194,3 +194,69 @@ def prove_files(zkey, wtns, r=b"\0" * 32, s=b"\0" * 32, nthreads=1, want_h=False
         raise RuntimeError("ora_prove_files rc=%d" % rc)
     js = buf.value.decode()
     return (js, h) if want_h else js
+
+
+# ---------------------------------------------------------------- pairing / Groth16 verification (oracle/pairing_ref.h)
+GT_BYTES = 384
+
+
+def _pairing_lib():
+    L = lib()
+    if not getattr(L, "_pairing_ready", False):
+        vp = C.c_void_p
+        L.ora_miller.argtypes = [vp, vp, vp]
+        L.ora_miller.restype = None
+        L.ora_pairing.argtypes = [vp, vp, vp]
+        L.ora_pairing.restype = C.c_int
+        L.ora_final_exp.argtypes = [vp, vp]
+        L.ora_final_exp.restype = C.c_int
+        L.ora_gt_mul.argtypes = [vp, vp, vp]
+        L.ora_gt_mul.restype = None
+        L.ora_groth16_verify.argtypes = [vp, vp, vp, vp, vp, C.c_uint32, vp, vp]
+        L.ora_groth16_verify.restype = C.c_int
+        L._pairing_ready = True
+    return L
+
+
+def _u8(b):
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def miller(g1_aff, g2_aff):
+    out = np.zeros(GT_BYTES, dtype=np.uint8)
+    _pairing_lib().ora_miller(_ptr(_u8(g1_aff)), _ptr(_u8(g2_aff)), _ptr(out))
+    return out.tobytes()
+
+
+def pairing(g1_aff, g2_aff):
+    out = np.zeros(GT_BYTES, dtype=np.uint8)
+    rc = _pairing_lib().ora_pairing(_ptr(_u8(g1_aff)), _ptr(_u8(g2_aff)), _ptr(out))
+    if rc:
+        raise RuntimeError("ora_pairing rc=%d" % rc)
+    return out.tobytes()
+
+
+def final_exp(f):
+    out = np.zeros(GT_BYTES, dtype=np.uint8)
+    rc = _pairing_lib().ora_final_exp(_ptr(_u8(f)), _ptr(out))
+    if rc:
+        raise RuntimeError("ora_final_exp rc=%d" % rc)
+    return out.tobytes()
+
+
+def gt_mul(a, b):
+    out = np.zeros(GT_BYTES, dtype=np.uint8)
+    _pairing_lib().ora_gt_mul(_ptr(_u8(a)), _ptr(_u8(b)), _ptr(out))
+    return out.tobytes()
+
+
+def groth16_verify(vk, proof, inputs):
+    """vk: dict(alpha1, beta2, gamma2, delta2, ic=[...]) of affine Montgomery bytes (groth16_io.vk_from_json);
+    proof: 256 B A | B | C; inputs: list of ints.  Returns True / False."""
+    ic = _u8(b"".join(vk["ic"]))
+    inp = _u8(b"".join(int(x).to_bytes(32, "little") for x in inputs)) if inputs else None
+    rc = _pairing_lib().ora_groth16_verify(_ptr(_u8(vk["alpha1"])), _ptr(_u8(vk["beta2"])), _ptr(_u8(vk["gamma2"])),
+                                           _ptr(_u8(vk["delta2"])), _ptr(ic), len(vk["ic"]), _ptr(_u8(proof)), _ptr(inp))
+    if rc < 0:
+        raise RuntimeError("ora_groth16_verify rc=%d" % rc)
+    return rc == 1

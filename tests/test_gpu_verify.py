@@ -1,0 +1,108 @@
+"""-m gpu : the batched Groth16 verifier (k16_vk_create / k16_verify_batch / k16_pairing_vec, csrc/verify.hip) through the
+C ABI, against the CPU oracle (oracle/pairing_ref.h, a restatement of ark-ec 0.4.2 / ark-groth16 0.4.0 pinned by
+tests/test_oracle_pairing.py).  Replaces prover-service/src/request_handler/prover_handler.rs:329-336."""
+import json
+
+import numpy as np
+import pytest
+
+import groth16_io as gio
+import oracle_lib as ol
+import pymodel as pm
+from test_oracle_prove import KNOWN_RS0
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import k16
+    c = k16.Context(0)
+    yield c
+    c.close()
+
+
+def test_pairing_values_bit_exact(ctx):
+    """e(P, Q) as 12 x 32 bytes equal to the oracle's for multiples of the generators, zero points included (a zero P
+    or Q gives 1, as ark-ec's multi_miller_loop skips the pair); 70 pairs = more than one wavefront."""
+    import k16
+    n = 70
+    g1 = ol.gen_points(0, 10, n)
+    g2 = ol.gen_points(1, 20, n)
+    g1[4] = 0
+    g2[5] = 0
+    g1[6] = 0
+    g2[6] = 0
+    got = k16.pairing_vec(ctx, g1, g2)
+    for i in range(n):
+        assert got[i].tobytes() == ol.pairing(bytes(g1[i]), bytes(g2[i])), i
+    # bilinearity on the device values: e(2P, 3Q) = e(P, Q)^6
+    one = ol.gen_points(0, 0, 2)
+    two = ol.gen_points(1, 0, 3)
+    e = k16.pairing_vec(ctx, np.stack([one[0], one[1]]), np.stack([two[0], two[2]]))
+    e6 = e[0].tobytes()
+    for _ in range(5):
+        e6 = ol.gt_mul(e6, e[0].tobytes())
+    assert e[1].tobytes() == e6
+
+
+def test_verify_toy_proofs_accept_reject(ctx, toy_paths):
+    """The reference's acceptance criterion on the GPU: toy proofs verify under toy_vk.json with public input 2
+    (prover-service/src/tests/prover_handler.rs:279-290), not with 3; tampered proofs are rejected; every flag equals
+    the oracle's."""
+    import k16
+    zkey, wtns, vkp = toy_paths
+    vk = gio.vk_from_json(vkp)
+    V = k16.VerifyingKey(ctx, vk)
+    known = gio.proof_from_json(KNOWN_RS0)
+    assert V.verify_batch([known], [[2]]) == [True]
+    assert V.verify_batch([known], [[3]]) == [False]
+    # proofs made by the GPU prover with fresh CSPRNG blinding
+    p = k16.Prover(ctx, zkey)
+    fresh = [gio.proof_from_json(p.prove_file(wtns)) for _ in range(5)]
+    p.close()
+    g2x = ol.gen_points(1, 77, 1)[0].tobytes()
+    d = json.loads(json.dumps(KNOWN_RS0))
+    d["pi_c"][0] = str((int(d["pi_c"][0]) + 1) % pm.Q)          # off the curve
+    cases = [(known, 2), (known, 3), (known, 2 + pm.R), (known, 0)]
+    cases += [(f, 2) for f in fresh] + [(fresh[0], 1)]
+    cases += [(known[192:256] + known[64:192] + known[0:64], 2)]  # A and C swapped
+    cases += [(known[:64] + g2x + known[192:], 2)]                # B replaced
+    cases += [(gio.proof_from_json(d), 2)]
+    cases += [(bytes(64) + known[64:], 2), (known[:64] + bytes(128) + known[192:], 2), (bytes(256), 2)]   # zero points
+    # a batch larger than a wavefront, accept and reject interleaved
+    cases = cases * 6
+    got = V.verify_batch([c[0] for c in cases], [[c[1]] for c in cases])
+    want = [ol.groth16_verify(vk, c[0], [c[1]]) for c in cases]
+    assert got == want
+    assert got[0] and not got[1] and got[2] and all(got[4:9]) and not any(got[9:15])
+    assert V.verify_batch([], []) == []
+    V.close()
+
+
+def test_verify_key_with_several_public_inputs(ctx):
+    """n_ic > 2: vk_x = IC[0] + sum x_i IC[i+1] on the device.  A consistent (vk, proof) pair is built from known
+    discrete logs: with A = aG, B = bH, C = cG, alpha = G, beta = H', gamma = H, delta = H the check reduces to
+    ab = alpha*beta' + vkx + c (exponents), which fixes c."""
+    import k16
+    g = ol.generator(0)
+    h = ol.generator(1)
+
+    def g1(k):
+        return ol.pt_to_affine(0, ol.mul_scalar(0, g, pm.limbs(k % pm.R)))
+
+    def g2(k):
+        return ol.pt_to_affine(1, ol.mul_scalar(1, h, pm.limbs(k % pm.R)))
+
+    ic_k = [11, 22, 33, 44]
+    xs = [5, pm.R - 3, 123456789]
+    al, be, a, b = 7, 9, 1001, 2002
+    vkx = ic_k[0] + sum(x * k for x, k in zip(xs, ic_k[1:]))
+    c = (a * b - al * be - vkx) % pm.R
+    vk = dict(alpha1=g1(al), beta2=g2(be), gamma2=g2(1), delta2=g2(1), ic=[g1(k) for k in ic_k])
+    proof = g1(a) + g2(b) + g1(c)
+    bad = g1(a) + g2(b) + g1(c + 1)
+    assert ol.groth16_verify(vk, proof, xs) and not ol.groth16_verify(vk, bad, xs)
+    V = k16.VerifyingKey(ctx, vk)
+    assert V.verify_batch([proof, bad, proof], [xs, xs, [xs[0], xs[1], xs[2] + 1]]) == [True, False, False]
+    V.close()
