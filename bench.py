@@ -221,6 +221,40 @@ def facade_leg(zpath, wpath, proofs):
                     "the reference's own metric (RS/fullprover.cpp:226-244, whole milliseconds)"}
 
 
+def verify_leg(ctx, k16, with_oracle):
+    """The batched GPU verifier (k16_verify_batch) on toy-circuit proofs made by the GPU prover: the only
+    key with a verification key offline; the cost of a Groth16 check does not depend on the circuit (3 pairings + one
+    scalar multiplication per public input; Keyless has one public input, like the toy circuit)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import groth16_io as gio
+    toy = os.path.join(ROOT, "tests", "golden", "toy")
+    vk = gio.vk_from_json(os.path.join(toy, "toy_vk.json"))
+    V = k16.VerifyingKey(ctx, vk)
+    p = k16.Prover(ctx, os.path.join(toy, "toy_1.zkey"))
+    proofs = [gio.proof_from_json(p.prove_file(os.path.join(toy, "toy.wtns"))) for _ in range(8)]
+    p.close()
+    out = {"entry": "k16_verify_batch", "key": "toy circuit (tests/golden/toy/toy_vk.json), 1 public input", "batches": []}
+    for n in (1, 64, 4096):
+        pr = [proofs[i % 8] for i in range(n)]
+        inp = [[2 if i % 5 else 3] for i in range(n)]         # every fifth proof gets the wrong public input
+        V.verify_batch(pr, inp)
+        t0 = time.perf_counter()
+        ok = V.verify_batch(pr, inp)
+        ms = (time.perf_counter() - t0) * 1e3
+        if ok != [bool(i % 5) for i in range(n)]:
+            raise SystemExit("bench.py: GPU verifier accepted / rejected the wrong proofs")
+        out["batches"].append({"n": n, "ms": ms, "proofs_per_s": n / ms * 1e3})
+    out["checked"] = True
+    if with_oracle:
+        import oracle_lib as ol
+        t0 = time.perf_counter()
+        for pr in proofs[:4]:
+            assert ol.groth16_verify(vk, pr, [2])
+        out["cpu_oracle_ms_per_proof"] = (time.perf_counter() - t0) / 4 * 1e3
+    V.close()
+    return out
+
+
 def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, scale=1.0):
     n_vars = max(int(KEYLESS["n_vars"] * scale), 8)
     N = 1 << max(int(np.ceil(np.log2(max(1376867 * scale, 4)))), 2)
@@ -288,6 +322,12 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             if got != want:
                 raise SystemExit("bench.py: GPU proof differs from the CPU oracle's")
         os.unlink(wpath)
+        try:
+            out["verify"] = verify_leg(ctx, k16, check_with_oracle)
+        except SystemExit:
+            raise
+        except Exception as e:
+            out["verify"] = {"error": repr(e)}
     prover.close()
     os.unlink(zpath)
     return out

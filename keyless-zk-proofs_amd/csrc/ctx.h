@@ -141,6 +141,7 @@ struct k16_ctx {
     // third wave would take stay free for the other lanes' sort / fold / reduction kernels, which otherwise wait for a
     // whole accumulate workgroup to retire before one of their waves fits.
     unsigned    acc_lds_bytes = 0;
+    unsigned    acc_grid_cap  = 0; // K16_ACC_GRID: at most this many (persistent, grid-stride) accumulate workgroups
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };
