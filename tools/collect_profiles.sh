@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects every measurement DESIGN.md / README quote for this round on the GPU box into gpurun_out/r02/ (copy the
+# summaries into profiles/r02/ afterwards).  Run through gpurun from the repository root.
+set -u
+O=gpurun_out/r02
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# 1. the driver's command, plain
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+python3 bench.py --steps 100 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_100steps.json 2>/dev/null
+# 2. the same command under rocprofv3 --kernel-trace --stats (kernel averages the roofline must agree with)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+# 3. PMC traffic, one counter per pass, one MSM at a time
+K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
+K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
+# 4. instruction-rate microbenchmarks (the multiply peak the ALU roofline uses)
+./tools/ubench > $O/ubench_instruction_rates.log 2>&1
+# 5. proofs: latency / throughput / facade, and the kernel statistics of a proof
+python3 tools/bench_proof.py --proofs 20 --facade 1 > $O/proof_keyless_shape.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/proof_stats -- python3 tools/bench_proof.py --proofs 10 > /dev/null 2> $O/proof_stats.err
+# 6. the multi-GPU code path on this one GPU: RCCL exchange forced at world size 1, and the strong-scaling leg (one 2^26 MSM)
+K16_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 40 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_force_dist_world1.json 2> $O/bench_force_dist_world1.err
+python3 bench.py --mode strong --total-log2n 26 --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > $O/bench_strong_2p26_1gpu.json 2> $O/bench_strong_2p26_1gpu.err
+python3 bench.py --gpus 2 --steps 2 --warmup 1 --proofs 0 > $O/bench_gpus2_on_1gpu_box.out 2>&1; echo "rc=$?" >> $O/bench_gpus2_on_1gpu_box.out
+# 7. verifier
+python3 tools/bench_verify.py > $O/verify.json 2> $O/verify.err
+ls -la $O
