@@ -111,7 +111,9 @@ def cpu_baseline(n_sample, scalars):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol  # the checker, used here only as the reported CPU baseline
 
-    threads = os.cpu_count() or 1   # the port parallelises over (window, point slice) pairs like the reference's TBB loop
+    # the port parallelises over (window, point slice) pairs like the reference's TBB loop; at 2^20 points it has 16 windows
+    # x 4 slices = 64 tasks (more slices cost more in the pack step than they spread), so more threads would only idle
+    threads = min(os.cpu_count() or 1, 64)
     bases = ol.gen_points(0, 0, n_sample)
     sc = np.ascontiguousarray(scalars[:n_sample])
     ol.msm(0, bases[:4096], sc[:4096], nthreads=threads)  # warm-up
@@ -312,7 +314,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             # the GPU's, and the byte-for-byte check of the GPU proof
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as ol
-            threads = os.cpu_count() or 1
+            threads = min(os.cpu_count() or 1, 96)
             t0 = time.time()
             want = ol.prove_files(zpath, wpath, r, s, nthreads=threads)
             cpu_s = time.time() - t0

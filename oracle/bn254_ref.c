@@ -326,6 +326,10 @@ static inline u64 bitrev(u64 x, unsigned bits)
     return r;
 }
 /* fft.cpp:170-219 : bit-reverse, then in-place DIT stages */
+/* threads for the butterfly / pointwise loops (the reference runs them under tbb::parallel_for, fft.cpp:202-218,
+ * groth16.cpp:160-275); 1 unless groth16_prove sets it */
+static int g_poly_threads = 1;
+
 static void ntt_fwd(const ntt_t* t, fe_t* a, u64 n)
 {
     unsigned dp = ilog2(n);
@@ -339,7 +343,9 @@ static void ntt_fwd(const ntt_t* t, fe_t* a, u64 n)
     }
     for (unsigned s = 1; s <= dp; s++) {
         u64 m = (u64)1 << s, md2 = m >> 1;
-        for (u64 i = 0; i < (n >> 1); i++) {
+#pragma omp parallel for schedule(static) num_threads(g_poly_threads) if (n >= 8192 && g_poly_threads > 1)
+        for (int64_t ii = 0; ii < (int64_t)(n >> 1); ii++) {
+            u64  i = (u64)ii;
             u64  k = (i / md2) * m, j = i % md2;
             fe_t tt, u;
             fe_mul(FR, &tt, ntt_root(t, s, j), &a[k + j + md2]);
@@ -356,7 +362,9 @@ static void ntt_inv(const ntt_t* t, fe_t* a, u64 n)
     unsigned    dp  = ilog2(n);
     u64         nd2 = n >> 1;
     const fe_t* sc  = &t->pow2inv[dp];
-    for (u64 i = 1; i < nd2; i++) {
+#pragma omp parallel for schedule(static) num_threads(g_poly_threads) if (n >= 8192 && g_poly_threads > 1)
+    for (int64_t ii = 1; ii < (int64_t)nd2; ii++) {
+        u64  i   = (u64)ii;
         u64  r   = n - i;
         fe_t tmp = a[i];
         fe_mul(FR, &a[i], &a[r], sc);
@@ -538,7 +546,9 @@ static int groth16_prove(const zkey_view_t* z, const fe_t* wtns, const uint8_t r
         fe_add(FR, &ab[cf.c], &ab[cf.c], &aux);
     }
     /* groth16.cpp:160-167 */
-    for (u64 i = 0; i < N; i++) fe_mul(FR, &c[i], &a[i], &b[i]);
+    g_poly_threads = nthreads < 1 ? 1 : nthreads;
+#pragma omp parallel for schedule(static) num_threads(g_poly_threads) if (N >= 8192 && g_poly_threads > 1)
+    for (int64_t i = 0; i < (int64_t)N; i++) fe_mul(FR, &c[i], &a[i], &b[i]);
 
     ntt_t ntt;
     int   rc = ntt_init(&ntt, 2 * N); /* groth16.hpp:96 */
@@ -549,15 +559,18 @@ static int groth16_prove(const zkey_view_t* z, const fe_t* wtns, const uint8_t r
     for (int k = 0; k < 3; k++) {
         fe_t* x = vec[k];
         ntt_inv(&ntt, x, N);
-        for (u64 i = 0; i < N; i++) fe_mul(FR, &x[i], &x[i], ntt_root(&ntt, dp + 1, i));
+#pragma omp parallel for schedule(static) num_threads(g_poly_threads) if (N >= 8192 && g_poly_threads > 1)
+        for (int64_t i = 0; i < (int64_t)N; i++) fe_mul(FR, &x[i], &x[i], ntt_root(&ntt, dp + 1, (u64)i));
         ntt_fwd(&ntt, x, N);
     }
     /* groth16.cpp:266-275 */
-    for (u64 i = 0; i < N; i++) {
+#pragma omp parallel for schedule(static) num_threads(g_poly_threads) if (N >= 8192 && g_poly_threads > 1)
+    for (int64_t i = 0; i < (int64_t)N; i++) {
         fe_mul(FR, &a[i], &a[i], &b[i]);
         fe_sub(FR, &a[i], &a[i], &c[i]);
         fe_from_mont(FR, &a[i], &a[i]);
     }
+    g_poly_threads = 1;
     if (h_scalars_out) memcpy(h_scalars_out, a, N * sizeof(fe_t));
     /* groth16.cpp:281-283 */
     g1_msm(&pih, z->pH, (const uint8_t*)a, sW, N, nthreads);

@@ -95,3 +95,17 @@ def test_synthetic_circuit_h_scalars_against_python_model(tmp_path):
     A, B, C = to_coset(a), to_coset(b), to_coset(cc)
     want = [(x * y - z) % pm.R for x, y, z in zip(A, B, C)]
     assert got == want
+
+
+def test_threads_do_not_change_proof_or_h_at_parallel_sizes(tmp_path):
+    """N >= 8192 switches the oracle's butterfly / pointwise loops and its MSM slices to OpenMP (the reference runs the
+    same loops under tbb::parallel_for): proof JSON and H scalars must not depend on the thread count."""
+    import numpy as np
+    import zkey_builder as zb
+    zk, wt = str(tmp_path / "s.zkey"), str(tmp_path / "s.wtns")
+    zb.build_zkey(zk, 20000, 1, 1 << 15, 60000, seed=3)
+    zb.build_wtns(wt, 20000, seed=4)
+    r, s = pm.limbs(5), pm.limbs(7)
+    a, h1 = ol.prove_files(zk, wt, r, s, nthreads=1, want_h=True)
+    b, h2 = ol.prove_files(zk, wt, r, s, nthreads=8, want_h=True)
+    assert a == b and np.array_equal(h1, h2)
