@@ -257,6 +257,10 @@ def verify_leg(ctx, k16, with_oracle):
     return out
 
 
+def ctx_device(ctx):
+    return getattr(ctx, "device", 0)
+
+
 def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, scale=1.0):
     n_vars = max(int(KEYLESS["n_vars"] * scale), 8)
     N = 1 << max(int(np.ceil(np.log2(max(1376867 * scale, 4)))), 2)
@@ -293,6 +297,46 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         allv = [None] * world
         dist.all_gather_object(allv, lat)
         lat = [x for l in allv for x in l]
+    # throughput mode (rank 0 reports, every rank runs it so that the GPUs stay symmetric): three provers -- own context,
+    # streams and resident key each -- share this GPU and prove concurrently from three threads, the deployment of
+    # INTEGRATION.md section 4 (K16_DEVICES=0,0,0 behind one FullProver).  One proof's upload / chain / H MSM then runs
+    # under another's; latency per proof rises, proofs per second too.
+    thr = None
+    n_conc = int(os.environ.get("K16_BENCH_PROVERS", "3"))
+    if n_conc > 1:
+        import threading
+        others = [k16.Context(ctx_device(ctx)) for _ in range(n_conc - 1)]
+        provers = [prover] + [k16.Prover(c, zpath) for c in others]
+        for pv in provers[1:]:
+            pv.prove_mem(wits[0], r, s)
+        lats = [[] for _ in provers]
+
+        def worker(i):
+            for k in range(proofs):
+                t1 = time.perf_counter()
+                provers[i].prove_mem(wits[(i + k) % len(wits)])
+                lats[i].append((time.perf_counter() - t1) * 1e3)
+
+        if dist is not None:
+            dist.barrier()
+        t_all = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(n_conc)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t_all
+        allv = [x for l in lats for x in l]
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        thr = {"provers_per_gpu": n_conc, "proofs_per_s": world * n_conc * proofs / el, "p50_ms": float(np.median(allv)),
+               "p99_ms": float(np.percentile(allv, 99)), "proofs": world * n_conc * proofs}
+        for pv in provers[1:]:
+            pv.close()
+        for c in others:
+            c.close()
     out = None
     if rank == 0:
         out = {"proofs_per_s": world * proofs / elapsed, "p50_ms": float(np.median(lat)),
@@ -300,7 +344,8 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
                "n_vars": n_vars, "domain": N, "n_coefs": n_coefs, "n_public": 1,
                "key": "synthetic, Keyless shape (the real zkey is not available offline); one resident copy per GPU",
                "parallelism": "replicas: one prover per GPU, no collective" if world > 1 else "single GPU",
-               "setup_s": {"synthesize_key": t_key, "prover_create": t_create}, "checked": None}
+               "setup_s": {"synthesize_key": t_key, "prover_create": t_create}, "checked": None,
+               "throughput_mode": thr}
         wpath = "/tmp/k16_bench_%d.wtns" % os.getpid()
         write_wtns(wpath, wits[0])
         got = prover.prove_mem(wits[0], r, s)

@@ -154,6 +154,7 @@ class Context:
         if rc:
             raise K16Error(rc, "k16_ctx_create(device=%d): no usable HIP device" % device)
         self.h = h
+        self.device = device
 
     def close(self):
         if self.h:
