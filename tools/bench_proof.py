@@ -18,66 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "keyless-zk-proofs_amd"))
 import k16  # noqa: E402
 
-Q = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
-R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+sys.path.insert(0, ROOT)
+import bench as _bench  # noqa: E402  (the synthetic Keyless-shape key and witness are bench.py's)
 
-
-def le32(x):
-    return x.to_bytes(32, "little")
-
-
-def section(t, payload):
-    return struct.pack("<IQ", t, len(payload)) + payload
+R = _bench.R_MOD
+le32 = _bench._le32
+section = _bench._section
 
 
 def synth_zkey_bytes(ctx, n_vars, n_public, N, n_coefs, seed=1):
-    rs = np.random.RandomState(seed)
-
-    def pts(group, start, n, zero_frac=0.0):
-        d = ctx.synth_points(group, start, n)
-        a = d.download(np.uint8, (n, k16.AFF_BYTES[group])).copy()
-        d.free()
-        if zero_frac > 0:
-            a[rs.rand(n) < zero_frac] = 0
-        return a.tobytes()
-
-    g1 = pts(k16.G1, 100, 3)
-    g2 = pts(k16.G2, 50, 3)
-    hdr = struct.pack("<I", 32) + le32(Q) + struct.pack("<I", 32) + le32(R) + struct.pack("<III", n_vars, n_public, N)
-    hdr += g1[0:64] + g1[64:128] + g2[0:128] + g2[128:256] + g1[128:192] + g2[256:384]
-    # coefficients: snarkjs order (by constraint, then matrix); values = small ints * R^2 mod r
-    coef = np.zeros(n_coefs, dtype=[("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "V32")])
-    coef["m"] = rs.randint(0, 2, size=n_coefs)
-    coef["c"] = np.sort(rs.randint(0, N, size=n_coefs))
-    coef["s"] = rs.randint(0, n_vars, size=n_coefs)
-    r2 = pow(1 << 256, 2, R)
-    table = np.frombuffer(b"".join(le32(v * r2 % R) for v in range(1, 257)), dtype="V32")
-    coef["v"] = table[rs.randint(0, 256, size=n_coefs)]
-    secs = [section(1, struct.pack("<I", 1)), section(2, hdr),
-            section(4, struct.pack("<I", n_coefs) + coef.tobytes()),
-            section(5, pts(k16.G1, 1000, n_vars)),
-            section(6, pts(k16.G1, 3000000, n_vars, 0.5)),
-            section(7, pts(k16.G2, 5000, n_vars, 0.5)),
-            section(8, pts(k16.G1, 6000000, n_vars - n_public - 1)),
-            section(9, pts(k16.G1, 9000000, N))]
-    return b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(secs)
+    return _bench.synth_zkey_bytes(ctx, k16, n_vars, n_public, N, n_coefs, seed)
 
 
-def synth_witness(n_vars, seed):
-    rs = np.random.RandomState(seed)
-    w = np.zeros((n_vars, 32), dtype=np.uint8)
-    u = rs.rand(n_vars)
-    bits = u < 0.90
-    w[bits, 0] = rs.randint(0, 2, size=int(bits.sum()))
-    byts = (u >= 0.90) & (u < 0.98)
-    w[byts, 0] = rs.randint(0, 256, size=int(byts.sum()))
-    full = u >= 0.98
-    f = rs.randint(0, 256, size=(int(full.sum()), 32), dtype=np.uint8)
-    f[:, 31] &= 0x1F
-    w[full] = f
-    w[0] = 0
-    w[0, 0] = 1
-    return w
+synth_witness = _bench.synth_witness
 
 
 def main():
