@@ -637,6 +637,12 @@ def main():
     proof = None
     ctx.set_option(k16.OPT_PIPELINED_MSM, 0)   # the prover wants the latency-tuned defaults (include/k16.h)
     if args.proofs > 0:
+        # the prover gets a context of its own, as in a service: the MSM bench's context has four lane streams, and a stream
+        # the prover never uses still costs a proof ~0.4 ms (p50 7.9 vs 7.5 ms measured; ROCm multiplexes a process's streams
+        # onto its hardware queues)
+        if not os.environ.get("K16_BENCH_PROOF_SAME_CTX"):
+            ctx.close()
+            ctx = k16.Context(dev)
         proof = proof_leg(ctx, k16, torch, dist, rank, world, args.proofs,
                           check_with_oracle=(world == 1 and not args.no_cpu_baseline), scale=args.proof_scale)
 
