@@ -568,7 +568,7 @@ def main():
     # unchanged).  A fresh process needs ~40 MSMs before it runs at its steady rate: every lane's first MSM allocates its
     # workspaces (5-12 ms each), and the GPU's clocks ramp up over the first ~30 ms of load (per-step time 1.83 -> 1.65 ms,
     # gpurun_out traces in profiles/r02/); with W = 5 the driver's 20 timed steps would measure mostly that ramp.
-    prewarm = int(os.environ.get("K16_BENCH_PREWARM", "48"))
+    prewarm = int(os.environ.get("K16_BENCH_PREWARM", "48" if n <= (1 << 21) else "2"))   # large shards: seconds per MSM
     if prewarm:
         run(prewarm)
     if args.warmup:
