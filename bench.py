@@ -40,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "keyless-zk-proofs_amd"))
 
 LOG2N = 20
+SHARE_GPU = False
+XDEV = "cuda"
 Q_MOD = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
 R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 ALGO_BYTES_PER_POINT = 64 + 32  # G1 MSM = n x (64 B affine point + 32 B scalar)
@@ -291,7 +293,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_all
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=XDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         allv = [None] * world
@@ -328,7 +330,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         el = time.perf_counter() - t_all
         allv = [x for l in lats for x in l]
         if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            t = torch.tensor([el], dtype=torch.float64, device=XDEV)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         thr = {"provers_per_gpu": n_conc, "proofs_per_s": world * n_conc * proofs / el, "p50_ms": float(np.median(allv)),
@@ -432,15 +434,26 @@ def main():
     import torch  # device plumbing + torch.distributed (RCCL); loaded first so one HIP runtime is shared
     import k16
 
+    global SHARE_GPU, XDEV
+    SHARE_GPU = bool(os.environ.get("K16_BENCH_SHARE_GPU"))
+    XDEV = "cpu" if SHARE_GPU else "cuda"     # where the 128-byte exchange and the timing reductions live
+
     dist = None
     if world > 1 or os.environ.get("K16_BENCH_FORCE_DIST"):  # the env knob exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = local_rank if world > 1 else 0
+        # K16_BENCH_SHARE_GPU=1 (test rig for the N > 1 code path on a one-GPU box): every rank uses GPU 0 and the exchange
+        # runs over gloo (RCCL refuses two ranks on one device); the sharding, the fold, the closed-form check over all
+        # ranks and the replica proof leg are the same code as with one GPU per rank
+        if SHARE_GPU:
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    dev = local_rank if (world > 1 and not SHARE_GPU) else 0
     ctx = k16.Context(dev)  # raises without a GPU / library: there is no CPU fallback
     strong = args.mode == "strong"
     depth_default = "1" if strong else "4"
@@ -494,7 +507,7 @@ def main():
         if dist is not None:
             # the path's one exchange: start this step's all_gather, complete the previous step's (it ran under the
             # GPU work enqueued in between); run() drains the last one inside the timed region
-            pending_x.append(sharding.exchange_start(dist, k16.G1, xyzz, device="cuda"))
+            pending_x.append(sharding.exchange_start(dist, k16.G1, xyzz, device=None if SHARE_GPU else "cuda"))
             if len(pending_x) > 1:
                 xyzz, _ = sharding.exchange_finish(pending_x.pop(0))
         return xyzz
@@ -611,7 +624,7 @@ def main():
 
     ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=XDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         ranks_seen = dist.get_world_size()
@@ -689,8 +702,8 @@ def main():
                 "bases": "fixed-base window tables (k16_msm_fixed_base_prepare)" if fixed_tab is not None
                          else "prepared once (k16_msm_bases_prepare)" if prepared is not None
                          else "reference format (Montgomery affine), converted inside every step",
-                "sharding": "contiguous shards (sharding.shard_range) + RCCL all_gather of 128-B partials + EC-add fold"
-                            if dist is not None else "single GPU",
+                "sharding": ("contiguous shards (sharding.shard_range) + %s all_gather of 128-B partials + EC-add fold"
+                             % ("gloo (test rig: all ranks on GPU 0)" if SHARE_GPU else "RCCL")) if dist is not None else "single GPU",
             },
             "roofline": {
                 "kernel": "k_accumulate<Eng9> (bucket accumulation, XYZZ mixed adds)",
