@@ -268,11 +268,17 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
     N = 1 << max(int(np.ceil(np.log2(max(1376867 * scale, 4)))), 2)
     n_coefs = int(KEYLESS["n_coefs"] * scale)
     t0 = time.time()
-    zk = synth_zkey_bytes(ctx, k16, n_vars, 1, N, n_coefs)
-    zpath = "/tmp/k16_bench_%d_%d.zkey" % (os.getpid(), rank)
-    with open(zpath, "wb") as f:
-        f.write(zk)
-    del zk
+    # one key file per job: rank 0 writes it, every rank of the node loads it (0.93 GB at Keyless shape)
+    tag = os.environ.get("MASTER_PORT", str(os.getpid())) if dist is not None else str(os.getpid())
+    zpath = "/tmp/k16_bench_%s.zkey" % tag
+    if rank == 0:
+        zk = synth_zkey_bytes(ctx, k16, n_vars, 1, N, n_coefs)
+        with open(zpath + ".part", "wb") as f:
+            f.write(zk)
+        os.replace(zpath + ".part", zpath)
+        del zk
+    if dist is not None:
+        dist.barrier()
     t_key = time.time() - t0
     t0 = time.time()
     prover = k16.Prover(ctx, zpath)
@@ -378,7 +384,10 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         except Exception as e:
             out["verify"] = {"error": repr(e)}
     prover.close()
-    os.unlink(zpath)
+    if dist is not None:
+        dist.barrier()          # nobody is still opening the key
+    if rank == 0:
+        os.unlink(zpath)
     return out
 
 
