@@ -736,9 +736,10 @@ def main():
                              "v_mad_u64_u32-bound multiply rate of the radix-2^29 field (no MFMA path exists for 254-bit integers)",
                 },
                 "note": "kernel_ms is the live average inside the timed region (HIP events on the kernel's stream; up to "
-                        "four MSMs share the GPU, so the other lanes' sort / reduction kernels run beside it); "
-                        "kernel_ms_isolated is the same kernel with one MSM at a time. Integer-multiply-issue bound in "
-                        "practice; see DESIGN.md (modmul-rate view)",
+                        "four MSMs share the GPU, and the other lanes' sort / reduction kernels run beside it at a higher "
+                        "wave priority, so their instructions are issued inside this interval: +0.3 ms over isolated, "
+                        "+2 % points/s over not prioritising them); kernel_ms_isolated is the same kernel with one MSM at a "
+                        "time. Integer-multiply-issue bound in practice; see DESIGN.md (modmul-rate view)",
             },
             "stage_ms_isolated": stage_ms,
             "host_ms": host_ms,
