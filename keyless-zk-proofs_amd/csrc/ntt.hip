@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) k_build_roots(Fr* __restrict__ roots, uin
 // fft.cpp:170-189
 __global__ void __launch_bounds__(256) k_bitrev(Fr* __restrict__ a, uint32_t logn)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << logn)) return;
     uint32_t r = __brev(i) >> (32 - logn);
@@ -115,6 +116,7 @@ template <bool CONV_IN, bool CONV_OUT>
 __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr* __restrict__ roots9, uint32_t s0,
                                                    uint32_t K, uint32_t TL, uint32_t S)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     extern __shared__ uint4 ntt_lds[];
     Fr9*           tile  = reinterpret_cast<Fr9*>(ntt_lds);
     const uint32_t T     = 1u << TL;
@@ -200,6 +202,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
 // fft.cpp:226-245 on packed R' data
 __global__ void __launch_bounds__(256) k_inv_tail9(Fr* __restrict__ a, uint32_t logn, Fr9 scale)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t n = 1u << logn;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > (n >> 1)) return;
@@ -343,6 +346,7 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
 __global__ void __launch_bounds__(256) k_tail_shift_bitrev9(const Fr* __restrict__ src, Fr* __restrict__ dst, uint32_t logn,
                                                             Fr9 scale, const Fr* __restrict__ roots9, uint32_t stride_log)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     const uint32_t n = 1u << logn;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_p
                                               const Fr* __restrict__ coef9, const Fr* __restrict__ wtns,
                                               Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N, uint32_t logN)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * N) return;
     uint32_t lo = row_ptr[t], hi = row_ptr[t + 1];
@@ -146,6 +147,7 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_p
 __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __restrict__ a, const Fr* __restrict__ b,
                                              uint32_t N)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) st_r9(&c[i], frmul9(ld_r9(&a[i]), ld_r9(&b[i])));
 }
@@ -153,6 +155,7 @@ __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __res
 __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr* __restrict__ a,
                                                   const Fr* __restrict__ b, const Fr* __restrict__ c, uint32_t N)
 {
+    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) st_fr(&out[i], fr9_to_standard(frsub9(frmul9(ld_r9(&a[i]), ld_r9(&b[i])), ld_r9(&c[i]))));
 }
