@@ -383,7 +383,10 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_A, std::max<size_t>(nv * 64, 64)), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_B1, std::max<size_t>(nv * 64, 64)), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_B2, std::max<size_t>(nv * 128, 128)), p);
-    K16_HIP_P(ctx, hipMalloc((void**)&p->d_C, std::max<size_t>(nc * 64, 64)), p);
+    // the C table is stored with n_public + 1 leading (0,0) rows, i.e. indexed by WIRE like A / B1 / B2: the C MSM
+    // (groth16.cpp:106-112: points C[0..), scalars wtns + n_public + 1) then runs over the whole witness and shares the A
+    // MSM's bucket sort instead of sorting the same scalars, shifted by two, once more; (0,0) rows contribute nothing
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_C, std::max<size_t>(nv * 64, 64)), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_H, (size_t)N * 64), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_rowptr, rowptr.size() * 4), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_wire, wire.size() * 4), p);
@@ -397,7 +400,8 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_A, bv.sec[5].p, nv * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_B1, bv.sec[6].p, nv * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_B2, bv.sec[7].p, nv * 128, hipMemcpyHostToDevice, st), p);
-    if (nc) K16_HIP_P(ctx, hipMemcpyAsync(p->d_C, bv.sec[8].p, nc * 64, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemsetAsync(p->d_C, 0, (nv - nc) * 64, st), p);
+    if (nc) K16_HIP_P(ctx, hipMemcpyAsync(p->d_C + (nv - nc), bv.sec[8].p, nc * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_H, bv.sec[9].p, (size_t)N * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_wire, wire.data(), wire.size() * 4, hipMemcpyHostToDevice, st), p);
@@ -420,7 +424,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     if ((rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_A, nv, p->d_A)) ||
         (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_B1, nv, p->d_B1)) ||
         (rc = k16_msm_bases_prepare(ctx, K16_G2, p->d_B2, nv, p->d_B2)) ||
-        (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_C, nc, p->d_C)) ||
+        (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_C, nv, p->d_C)) ||
         (rc = k16_msm_bases_prepare(ctx, K16_G1, p->d_H, N, p->d_H))) {
         prover_free(p);
         return rc;
@@ -606,7 +610,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     if (p->n_vars < (1u << 17)) wc = 0; // small circuits: automatic
     // All five MSMs are enqueued back to back; their host tails (conversion + Horner, ~0.3 ms each, ~1.2 ms for
     // G2) run while later MSMs occupy the GPU.
-    // Lane 0: A, B1; lane 2: B2 (A's bucket sort serves all three).  Lane 1: C, then H once the polynomial chain is
+    // Lane 0: A, B1; lane 2: B2; lane 1: C (A's bucket sort serves all four), then H once the polynomial chain is
     // done.  The fold and weighted-sum stages of one lane leave most CUs idle; the other lanes' kernels fill them.
     struct LaneReset {
         k16_ctx* c;
@@ -618,10 +622,10 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         ForcedC fc(ctx, wc);
         ctx->cur_lane = 0;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars))) return rc;
-        ctx->cur_lane = 1;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns + (p->n_public + 1),
-                                           (uint64_t)p->n_vars - p->n_public - 1)))
-            return rc;
+        ctx->cur_lane        = 1;
+        ctx->reuse_sort      = true; // C is indexed by wire (see k16_prover_create_mem): same scalars, same sort
+        ctx->reuse_sort_lane = 0;
+        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, p->n_vars))) return rc;
         ctx->cur_lane   = 0;
         ctx->reuse_sort = true;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
