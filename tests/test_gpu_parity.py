@@ -722,3 +722,29 @@ def test_prover_failure_leaves_no_stale_msms(ctx, tmp_path, monkeypatch):
     d_b.free()
     d_s.free()
     p.close()
+
+
+def test_msm_with_hip_graphs_option(ctx):
+    """K16_OPT_GRAPHS: sort and fold + reduction replayed as HIP graphs after their second use (per lane, shape and
+    staging slot).  Results must not change, across repeated calls (eager, capture, replay) and lanes."""
+    import k16
+    n = 20000
+    bases = ol.gen_points(0, 9, n)
+    sc = [np_scalars(700 + i, n, "uniform") for i in range(2)]
+    want = [ol.msm(0, bases, s, nthreads=8)[1] for s in sc]
+    d_b = ctx.to_device(bases)
+    d_s = [ctx.to_device(s) for s in sc]
+    ctx.set_option(k16.OPT_GRAPHS, 1)
+    try:
+        for rep in range(5):
+            for lane in (0, 1):
+                ctx.set_lane(lane)
+                for i in range(2):
+                    ctx.msm_enqueue(k16.G1, d_b, d_s[i], n)
+                for i in range(2):
+                    assert ctx.msm_finish(k16.G1)[1] == want[i], (rep, lane, i)
+    finally:
+        ctx.set_option(k16.OPT_GRAPHS, 0)
+        ctx.set_lane(0)
+    for d in d_s + [d_b]:
+        d.free()
