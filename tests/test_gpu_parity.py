@@ -748,3 +748,41 @@ def test_msm_with_hip_graphs_option(ctx):
         ctx.set_lane(0)
     for d in d_s + [d_b]:
         d.free()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "full256", "witness"])
+def test_msm_g1_2p20_vs_oracle(ctx, kind):
+    """BASELINE config 2 at its stated size against the oracle directly (not only through closed forms): 2^20 points,
+    uniform scalars below r, arbitrary 256-bit scalars (top window + carry window in use), witness-like scalars."""
+    n = 1 << 20
+    bases = ol.gen_points(0, 3, n)
+    bases[5] = 0
+    bases[7] = bases[6]
+    _check_msm(ctx, 0, bases, np_scalars(801, n, kind), threads=os.cpu_count() or 8)
+
+
+def test_msm_fixed_base_2p21_vs_oracle(ctx):
+    """The H MSM's configuration (n = 2^21, c = 20, 13 window tables) against the oracle itself."""
+    import k16
+    n = 1 << 21
+    bases = ol.gen_points(0, 11, n)
+    d_b = ctx.to_device(bases)
+    d_t, c = ctx.fixed_base_prepare(k16.G1, d_b, n)
+    assert c == 20
+    sc = np_scalars(902, n, "uniform")
+    _, want = ol.msm(0, bases, sc, nthreads=os.cpu_count() or 8)
+    assert _fixed_base_msm(ctx, d_t, sc, n)[1] == want
+    d_t.free()
+    d_b.free()
+
+
+@pytest.mark.parametrize("log2n", [17, 19, 20])
+def test_ntt_large_sizes_vs_oracle(ctx, log2n):
+    """Sizes between the small-size sweep (<= 2^16) and the Keyless domain (2^21): every pass split (10 + 7, 10 + 6 + 3,
+    10 + 6 + 4 stages) against the oracle, forward and inverse, with the table of twice the size."""
+    n = 1 << log2n
+    rs = np.random.RandomState(log2n)
+    a = rs.randint(0, 2 ** 63, size=(n, 4)).astype(np.uint64)
+    a[:, 3] &= (1 << 60) - 1
+    for inverse in (False, True):
+        assert np.array_equal(ctx.ntt(a, max_domain=2 * n, inverse=inverse), ol.ntt(a, max_domain=2 * n, inverse=inverse))
