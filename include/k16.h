@@ -155,6 +155,9 @@ int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_domain, int i
 /* ---- synthetic inputs: d_out[i] = (start + i + 1) * G, affine Montgomery (the point family of the
  * reference's own MSM test, alt_bn128_test.cpp:183-190); used by bench.py and the full-size tests ---- */
 int k16_synth_points(k16_ctx* ctx, int group, uint64_t start, uint64_t n, void* d_out_affine);
+/* d_out[i] = scalar_i * G for n arbitrary 256-bit scalars (device, 32 B little-endian standard form): lets a test build a
+ * Groth16 key from a known trapdoor, i.e. a synthetic key of any size whose proofs verify (tests/valid_key_builder.py) */
+int k16_synth_points_scalars(k16_ctx* ctx, int group, const void* d_scalars, uint64_t n, void* d_out_affine);
 
 /* ---- batch primitives, for parity tests of the device arithmetic ---- */
 int k16_field_op_vec(k16_ctx* ctx, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n);

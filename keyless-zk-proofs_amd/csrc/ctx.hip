@@ -419,37 +419,76 @@ __global__ void __launch_bounds__(64) k_synth_points(Aff<F> gen, uint64_t start,
     out[i] = to_affine(acc);
 }
 
+// out[i] = scalars[i] * G for arbitrary 256-bit scalars (32 B little-endian, standard form): the trapdoor side of a
+// synthetic Groth16 set-up (tests/valid_key_builder.py builds keys whose proofs VERIFY from known tau, alpha, beta ...)
+template <class F>
+__global__ void __launch_bounds__(64) k_synth_points_scalars(Aff<F> gen, const uint8_t* __restrict__ scalars, uint64_t n,
+                                                             Aff<F>* __restrict__ out)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t k[32];
+    for (int b = 0; b < 32; b++) k[b] = scalars[i * 32 + b];
+    out[i] = to_affine(pmul_scalar(Xyzz<F>::from_aff(gen), k));
+}
+
+static G1Aff g1_generator()
+{
+    G1Aff g;
+    g.x = Fq::one();                 // generator (1, 2)  (alt_bn128.hpp:41)
+    g.y = fdbl(Fq::one());
+    return g;
+}
+static G2Aff g2_generator()
+{
+    // G2 generator (alt_bn128.hpp:43-52): decimal constants converted on the host
+    static const char* const G2S[4] = {
+        "10857046999023057135944570762232829481370756359578518086990519993285655852781",
+        "11559732032986387107991004021392285783925812861821192530917403151452391805634",
+        "8495653923123431417604973247489272438418190587263600148770280649306958101930",
+        "4082367875863433681332203403145435568316851327593401208105741076214120093531"};
+    Fq v[4];
+    Fq ten = Fq::zero();
+    ten.v[0] = 10;
+    ten      = to_mont(ten);
+    for (int k = 0; k < 4; k++) {
+        Fq acc = Fq::zero();
+        for (const char* p = G2S[k]; *p; p++) {
+            Fq d  = Fq::zero();
+            d.v[0] = (uint32_t)(*p - '0');
+            acc   = fadd(fmul(acc, ten), to_mont(d));
+        }
+        v[k] = acc;
+    }
+    return G2Aff{Fq2{v[0], v[1]}, Fq2{v[2], v[3]}};
+}
+
+extern "C" int k16_synth_points_scalars(k16_ctx* c, int group, const void* d_scalars, uint64_t n, void* d_out_affine)
+{
+    if (!c || !d_scalars || !d_out_affine || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+    if (n == 0) return K16_OK;
+    K16_HIP(c, hipSetDevice(c->device));
+    unsigned grid = (unsigned)((n + 63) / 64);
+    if (group == K16_G1)
+        hipLaunchKernelGGL((k_synth_points_scalars<Fq>), dim3(grid), dim3(64), 0, c->stream, g1_generator(),
+                           (const uint8_t*)d_scalars, n, (G1Aff*)d_out_affine);
+    else
+        hipLaunchKernelGGL((k_synth_points_scalars<Fq2>), dim3(grid), dim3(64), 0, c->stream, g2_generator(),
+                           (const uint8_t*)d_scalars, n, (G2Aff*)d_out_affine);
+    K16_HIP(c, hipGetLastError());
+    return K16_OK;
+}
+
 extern "C" int k16_synth_points(k16_ctx* c, int group, uint64_t start, uint64_t n, void* d_out_affine)
 {
     if (!c || !d_out_affine || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     unsigned grid = (unsigned)((n + 63) / 64);
     if (group == K16_G1) {
-        G1Aff g;
-        g.x = Fq::one();                 // generator (1, 2)  (alt_bn128.hpp:41)
-        g.y = fdbl(Fq::one());
+        G1Aff g = g1_generator();
         hipLaunchKernelGGL((k_synth_points<Fq>), dim3(grid), dim3(64), 0, c->stream, g, start, n, (G1Aff*)d_out_affine);
     } else {
-        // G2 generator (alt_bn128.hpp:43-52): decimal constants converted on the host
-        static const char* const G2S[4] = {
-            "10857046999023057135944570762232829481370756359578518086990519993285655852781",
-            "11559732032986387107991004021392285783925812861821192530917403151452391805634",
-            "8495653923123431417604973247489272438418190587263600148770280649306958101930",
-            "4082367875863433681332203403145435568316851327593401208105741076214120093531"};
-        Fq v[4];
-        Fq ten = Fq::zero();
-        ten.v[0] = 10;
-        ten      = to_mont(ten);
-        for (int k = 0; k < 4; k++) {
-            Fq acc = Fq::zero();
-            for (const char* p = G2S[k]; *p; p++) {
-                Fq d  = Fq::zero();
-                d.v[0] = (uint32_t)(*p - '0');
-                acc   = fadd(fmul(acc, ten), to_mont(d));
-            }
-            v[k] = acc;
-        }
-        G2Aff g{Fq2{v[0], v[1]}, Fq2{v[2], v[3]}};
+        G2Aff g = g2_generator();
         hipLaunchKernelGGL((k_synth_points<Fq2>), dim3(grid), dim3(64), 0, c->stream, g, start, n, (G2Aff*)d_out_affine);
     }
     K16_HIP(c, hipGetLastError());

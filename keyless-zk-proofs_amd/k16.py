@@ -35,7 +35,7 @@ SYMBOLS = [
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
-    "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_field_op_vec", "k16_point_op_vec",
+    "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
     "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_pairing_vec",
@@ -94,6 +94,7 @@ def load():
     L.k16_ntt.argtypes = [vp, vp, u64, u64, i32]
     L.k16_ntt_host.argtypes = [vp, vp, u64, u64, i32]
     L.k16_synth_points.argtypes = [vp, i32, u64, u64, vp]
+    L.k16_synth_points_scalars.argtypes = [vp, i32, vp, u64, vp]
     L.k16_field_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
     L.k16_point_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
     L.k16_prover_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
@@ -265,6 +266,22 @@ class Context:
         self._chk(self.L.k16_synth_points(self.h, group, start, n, d.ptr))
         self.sync()
         return d
+
+    def synth_points_scalars(self, group, scalars):
+        """scalars: list of ints (any size, reduced mod r here) -> uint8 array (n, AFF_BYTES) of scalar_i * G."""
+        R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+        n = len(scalars)
+        if n == 0:
+            return np.zeros((0, AFF_BYTES[group]), dtype=np.uint8)
+        buf = np.frombuffer(b"".join((int(k) % R_MOD).to_bytes(32, "little") for k in scalars), dtype=np.uint8)
+        d_s = self.to_device(buf)
+        d_o = self.alloc(n * AFF_BYTES[group])
+        self._chk(self.L.k16_synth_points_scalars(self.h, group, d_s.ptr, n, d_o.ptr))
+        self.sync()
+        out = d_o.download(np.uint8, (n, AFF_BYTES[group])).copy()
+        d_s.free()
+        d_o.free()
+        return out
 
     # ---- NTT
     def ntt(self, a, max_domain=None, inverse=False):

@@ -106,3 +106,41 @@ def test_verify_key_with_several_public_inputs(ctx):
     V = k16.VerifyingKey(ctx, vk)
     assert V.verify_batch([proof, bad, proof], [xs, xs, [xs[0], xs[1], xs[2] + 1]]) == [True, False, False]
     V.close()
+
+
+def _gpu_points(ctx):
+    return lambda group, scalars: ctx.synth_points_scalars(group, scalars)
+
+
+@pytest.mark.parametrize("shape", [(12000, 1000, 300), (1209229, 107487, 26870)], ids=["2p14", "keyless_shape"])
+def test_proofs_of_a_valid_synthetic_key_verify(ctx, tmp_path, shape):
+    """A Groth16 key built from a known trapdoor (tests/valid_key_builder.py; points scalar * G made on the device): the
+    GPU prover's proofs must VERIFY -- the reference's acceptance criterion -- under the GPU verifier and under the oracle's,
+    with the right public input and not with a wrong one; with injected (r, s) they are also byte-equal to the oracle's.
+    The second shape is the Keyless circuit's: nVars 1,343,588, domain 2^21, 90 % bit / 8 % byte / 2 % full-width wires."""
+    import os
+    import k16
+    import valid_key_builder as vkb
+    key = vkb.build(_gpu_points(ctx), *shape, seed=7)
+    if shape[0] > 100000:
+        assert (key["n_vars"], key["domain"]) == (1343588, 1 << 21)
+    zk, wt = str(tmp_path / "v.zkey"), str(tmp_path / "v.wtns")
+    open(zk, "wb").write(key["zkey"])
+    vkb.write_wtns(wt, key["witness"])
+    x = key["public"][0]
+    p = k16.Prover(ctx, zk)
+    V = k16.VerifyingKey(ctx, key["vk"])
+    proofs = [gio.proof_from_json(p.prove_mem(key["witness"])) for _ in range(3)]      # CSPRNG blinding
+    assert len(set(proofs)) == 3
+    assert V.verify_batch(proofs + proofs, [[x]] * 3 + [[x + 1]] * 3) == [True] * 3 + [False] * 3
+    assert ol.groth16_verify(key["vk"], proofs[0], [x]) and not ol.groth16_verify(key["vk"], proofs[0], [x + 1])
+    r, s = pm.limbs(pm.SplitMix64(91).below(pm.R)), pm.limbs(pm.SplitMix64(92).below(pm.R))
+    got = p.prove_file(wt, r, s)
+    assert got == ol.prove_files(zk, wt, r, s, nthreads=os.cpu_count() or 8)
+    assert V.verify_batch([gio.proof_from_json(got)], [[x]]) == [True]
+    # a witness that violates one constraint: the proof is produced, and rejected
+    bad = key["witness"].copy()
+    bad[key["n_vars"] - 1, 0] ^= 1
+    assert V.verify_batch([gio.proof_from_json(p.prove_mem(bad))], [[x]]) == [False]
+    V.close()
+    p.close()

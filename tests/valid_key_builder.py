@@ -1,0 +1,170 @@
+"""Builds a VALID synthetic Groth16 key of any size -- circuit, trusted set-up from a known trapdoor, verification key,
+satisfying witness -- so that proofs of non-toy circuits can be checked the way the reference checks its proofs: they
+must VERIFY (prover-service/src/tests/prover_handler.rs:279-290, prover_handler.rs:329-336), not only equal the oracle's
+bytes.  The only verifying fixture the reference ships is the 3-wire toy circuit; the real Keyless key is not available
+offline.
+
+Circuit (R1CS over Fr), shaped like the Keyless witness (mostly bits, some bytes, a few full-width values):
+    wire 0 = 1, wire 1 = the public input, then n_bits bit wires, n_bytes free byte wires, n_prod product wires
+    bit wire i      : w_i * (w_i - 1) = 0                A = e_i, B = e_i - e_0, C = 0
+    product wire c  : (k1 w_a + k2 w_b) * (k3 w_d) = w_c   with a, b, d earlier wires and small k
+    and the nPublic + 1 rows snarkjs appends (A = e_i for the public wires, B = C = 0)
+Set-up with trapdoor (tau, alpha, beta, gamma, delta), exactly what the prover consumes:
+    A_i = [a_i(tau)]_1, B1_i = [b_i(tau)]_1, B2_i = [b_i(tau)]_2, C_i = [(beta a_i + alpha b_i + c_i)/delta]_1 (private wires),
+    IC_i = [(beta a_i + alpha b_i + c_i)/gamma]_1 (public wires),
+    H_i = [Z(tau) l_i(tau) / (Z(x_i) delta)]_1 with l_i the Lagrange basis of the odd coset x_i = g^(2i+1), g the primitive
+    2N-th root the prover's FFT uses (5^((r-1)/2N)), Z(x_i) = -2: the prover multiplies them with h_i = (A.B - C)(x_i)
+    (RS/groth16.cpp:172-283), so sum h_i H_i = [H(tau) Z(tau) / delta]_1.
+`points(group, scalars)` supplies scalar * generator for lists of scalars: the GPU (k16.Context.synth_points_scalars) for
+large keys, the oracle for small ones.
+"""
+import struct
+
+import numpy as np
+
+import pymodel as pm
+
+R = pm.R
+
+
+def _inv(x):
+    return pow(x, -1, R)
+
+
+def _batch_inv(v):
+    pref, acc = [0] * len(v), 1
+    for i, x in enumerate(v):
+        pref[i] = acc
+        acc = acc * x % R
+    inv = _inv(acc)
+    out = [0] * len(v)
+    for i in range(len(v) - 1, -1, -1):
+        out[i] = inv * pref[i] % R
+        inv = inv * v[i] % R
+    return out
+
+
+def _lagrange_at(t, N, omega):
+    """[L_j(t) for j < N] over the domain {omega^j}: (t^N - 1)/N * omega^j / (t - omega^j)."""
+    pw, u = [1] * N, 1
+    for j in range(N):
+        pw[j] = u
+        u = u * omega % R
+    dinv = _batch_inv([(t - x) % R for x in pw])
+    c = (pow(t, N, R) - 1) * _inv(N) % R
+    return [c * pw[j] % R * dinv[j] % R for j in range(N)]
+
+
+def _section(t, payload):
+    return struct.pack("<IQ", t, len(payload)) + payload
+
+
+def build(points, n_bits, n_bytes, n_prod, seed=1):
+    """Returns dict(zkey=bytes, vk=dict of affine Montgomery bytes (groth16_io format), witness=(n_vars, 32) uint8,
+    public=[int], n_vars, n_public, domain, n_coefs)."""
+    rng = pm.SplitMix64(seed)
+    n_public = 1
+    n_vars = 2 + n_bits + n_bytes + n_prod
+    M = n_bits + n_prod
+    N = 4
+    while N < M + n_public + 1:
+        N *= 2
+    # ---- witness
+    w = [0] * n_vars
+    w[0] = 1
+    w[1] = rng.next() | 1
+    bit0, byte0, prod0 = 2, 2 + n_bits, 2 + n_bits + n_bytes
+    for i in range(bit0, byte0):
+        w[i] = rng.next() & 1
+    for i in range(byte0, prod0):
+        w[i] = rng.next() & 0xFF
+    # ---- constraints: per row lists of (wire, coef)
+    rowsA, rowsB, rowsC = [], [], []
+    for i in range(bit0, byte0):
+        rowsA.append([(i, 1)])
+        rowsB.append([(i, 1), (0, R - 1)])
+        rowsC.append([])
+    for c in range(prod0, n_vars):
+        a, b, d = 1 + rng.next() % (c - 1), 1 + rng.next() % (c - 1), 1 + rng.next() % (c - 1)
+        k1, k2, k3 = 1 + rng.next() % 1000, 1 + rng.next() % 1000, 1 + rng.next() % 1000
+        w[c] = (k1 * w[a] + k2 * w[b]) % R * (k3 * w[d] % R) % R
+        rowsA.append([(a, k1), (b, k2)] if a != b else [(a, (k1 + k2) % R)])
+        rowsB.append([(d, k3)])
+        rowsC.append([(c, 1)])
+    for i in range(n_public + 1):       # snarkjs: one extra row per public wire (and the constant)
+        rowsA.append([(i, 1)])
+        rowsB.append([])
+        rowsC.append([])
+    assert len(rowsA) == M + n_public + 1 <= N
+    for ra, rb, rc in zip(rowsA, rowsB, rowsC):   # the witness satisfies the R1CS
+        dot = lambda row: sum(k * w[s] for s, k in row) % R
+        assert dot(ra) * dot(rb) % R == dot(rc)
+    # ---- trapdoor and QAP evaluations at tau
+    tau, alpha, beta, gamma, delta = (1 + rng.below(R - 1) for _ in range(5))
+    S = N.bit_length()                       # log2(2N)
+    g = pow(5, (R - 1) >> S, R)              # primitive 2N-th root (RS/fft.cpp:60-97: nqr = 5)
+    omega = g * g % R
+    L = _lagrange_at(tau, N, omega)
+    a_t, b_t, c_t = [0] * n_vars, [0] * n_vars, [0] * n_vars
+    coefs = []
+    r2 = pow(pm.MONT, 2, R)
+    for j, (ra, rb, rc) in enumerate(zip(rowsA, rowsB, rowsC)):
+        for s, k in ra:
+            a_t[s] = (a_t[s] + k * L[j]) % R
+            coefs.append((0, j, s, k))
+        for s, k in rb:
+            b_t[s] = (b_t[s] + k * L[j]) % R
+            coefs.append((1, j, s, k))
+        for s, k in rc:
+            c_t[s] = (c_t[s] + k * L[j]) % R
+    z_tau = (pow(tau, N, R) - 1) % R
+    # H_i = Z(tau) * l_i(tau) / (-2 delta),  l_i = Lagrange basis of the coset g * {omega^i}: L_i(tau / g)
+    Lc = _lagrange_at(tau * _inv(g) % R, N, omega)
+    hk = z_tau * _inv((R - 2) * delta % R) % R
+    s_h = [hk * x % R for x in Lc]
+    dinv, ginv = _inv(delta), _inv(gamma)
+    mix = [(beta * a_t[i] + alpha * b_t[i] + c_t[i]) % R for i in range(n_vars)]
+    s_c = [mix[i] * dinv % R for i in range(n_public + 1, n_vars)]
+    s_ic = [mix[i] * ginv % R for i in range(n_public + 1)]
+    # ---- points
+    pa = points(0, a_t)
+    pb1 = points(0, b_t)
+    pb2 = points(1, b_t)
+    pc = points(0, s_c)
+    ph = points(0, s_h)
+    pic = points(0, s_ic)
+    hdr1 = points(0, [alpha, beta, delta])
+    hdr2 = points(1, [beta, gamma, delta])
+    hdr = struct.pack("<I", 32) + pm.limbs(pm.Q) + struct.pack("<I", 32) + pm.limbs(R) + struct.pack("<III", n_vars, n_public, N)
+    hdr += bytes(hdr1[0]) + bytes(hdr1[1]) + bytes(hdr2[0]) + bytes(hdr2[1]) + bytes(hdr1[2]) + bytes(hdr2[2])
+    cf = np.zeros(len(coefs), dtype=[("m", "<u4"), ("c", "<u4"), ("s", "<u4"), ("v", "V32")])
+    cf["m"] = [x[0] for x in coefs]
+    cf["c"] = [x[1] for x in coefs]
+    cf["s"] = [x[2] for x in coefs]
+    cf["v"] = np.frombuffer(b"".join(pm.limbs(x[3] * r2 % R) for x in coefs), dtype="V32")
+    secs = [_section(1, struct.pack("<I", 1)), _section(2, hdr), _section(3, pic.tobytes()),
+            _section(4, struct.pack("<I", len(coefs)) + cf.tobytes()),
+            _section(5, pa.tobytes()), _section(6, pb1.tobytes()), _section(7, pb2.tobytes()),
+            _section(8, pc.tobytes()), _section(9, ph.tobytes())]
+    zkey = b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(secs)
+    vk = dict(alpha1=bytes(hdr1[0]), beta2=bytes(hdr2[0]), gamma2=bytes(hdr2[1]), delta2=bytes(hdr2[2]),
+              ic=[bytes(pic[i]) for i in range(n_public + 1)])
+    wit = np.frombuffer(b"".join(pm.limbs(x) for x in w), dtype=np.uint8).reshape(n_vars, 32).copy()
+    return dict(zkey=zkey, vk=vk, witness=wit, public=[w[1]], n_vars=n_vars, n_public=n_public, domain=N,
+                n_coefs=len(coefs))
+
+
+def oracle_points(group, scalars):
+    """scalar * G through the CPU oracle (small keys in CPU-only tests)."""
+    import oracle_lib as ol
+    g = ol.generator(group)
+    out = np.zeros((len(scalars), ol.AFF_BYTES[group]), dtype=np.uint8)
+    for i, k in enumerate(scalars):
+        out[i] = np.frombuffer(ol.pt_to_affine(group, ol.mul_scalar(group, g, pm.limbs(k % R))), dtype=np.uint8)
+    return out
+
+
+def write_wtns(path, wit):
+    sec1 = struct.pack("<I", 32) + pm.limbs(R) + struct.pack("<I", wit.shape[0])
+    with open(path, "wb") as f:
+        f.write(b"wtns" + struct.pack("<II", 2, 2) + _section(1, sec1) + _section(2, wit.tobytes()))
