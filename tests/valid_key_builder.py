@@ -62,24 +62,16 @@ def _section(t, payload):
 def build(points, n_bits, n_bytes, n_prod, seed=1):
     """Returns dict(zkey=bytes, vk=dict of affine Montgomery bytes (groth16_io format), witness=(n_vars, 32) uint8,
     public=[int], n_vars, n_public, domain, n_coefs)."""
-    rng = pm.SplitMix64(seed)
+    rng = pm.SplitMix64(seed)                 # circuit structure and trapdoor
     n_public = 1
     n_vars = 2 + n_bits + n_bytes + n_prod
     M = n_bits + n_prod
     N = 4
     while N < M + n_public + 1:
         N *= 2
-    # ---- witness
-    w = [0] * n_vars
-    w[0] = 1
-    w[1] = rng.next() | 1
     bit0, byte0, prod0 = 2, 2 + n_bits, 2 + n_bits + n_bytes
-    for i in range(bit0, byte0):
-        w[i] = rng.next() & 1
-    for i in range(byte0, prod0):
-        w[i] = rng.next() & 0xFF
     # ---- constraints: per row lists of (wire, coef)
-    rowsA, rowsB, rowsC = [], [], []
+    rowsA, rowsB, rowsC, prods = [], [], [], []
     for i in range(bit0, byte0):
         rowsA.append([(i, 1)])
         rowsB.append([(i, 1), (0, R - 1)])
@@ -87,7 +79,7 @@ def build(points, n_bits, n_bytes, n_prod, seed=1):
     for c in range(prod0, n_vars):
         a, b, d = 1 + rng.next() % (c - 1), 1 + rng.next() % (c - 1), 1 + rng.next() % (c - 1)
         k1, k2, k3 = 1 + rng.next() % 1000, 1 + rng.next() % 1000, 1 + rng.next() % 1000
-        w[c] = (k1 * w[a] + k2 * w[b]) % R * (k3 * w[d] % R) % R
+        prods.append((c, a, b, d, k1, k2, k3))
         rowsA.append([(a, k1), (b, k2)] if a != b else [(a, (k1 + k2) % R)])
         rowsB.append([(d, k3)])
         rowsC.append([(c, 1)])
@@ -96,9 +88,29 @@ def build(points, n_bits, n_bytes, n_prod, seed=1):
         rowsB.append([])
         rowsC.append([])
     assert len(rowsA) == M + n_public + 1 <= N
-    for ra, rb, rc in zip(rowsA, rowsB, rowsC):   # the witness satisfies the R1CS
-        dot = lambda row: sum(k * w[s] for s, k in row) % R
-        assert dot(ra) * dot(rb) % R == dot(rc)
+
+    def make_witness(wseed):
+        """A satisfying assignment (ints) for this circuit: free wires from wseed, product wires computed."""
+        rw = pm.SplitMix64(wseed)
+        w = [0] * n_vars
+        w[0] = 1
+        w[1] = rw.next() | 1
+        for i in range(bit0, byte0):
+            w[i] = rw.next() & 1
+        for i in range(byte0, prod0):
+            w[i] = rw.next() & 0xFF
+        for c, a, b, d, k1, k2, k3 in prods:
+            w[c] = (k1 * w[a] + k2 * w[b]) % R * (k3 * w[d] % R) % R
+        return w
+
+    def witness_bytes(w):
+        return np.frombuffer(b"".join(pm.limbs(x) for x in w), dtype=np.uint8).reshape(n_vars, 32).copy()
+
+    w = make_witness(seed * 1000003 + 1)
+    if n_vars <= 4096:                     # small keys: check every row (large ones: the proof verifying is the check)
+        for ra, rb, rc in zip(rowsA, rowsB, rowsC):
+            dot = lambda row: sum(k * w[s] for s, k in row) % R
+            assert dot(ra) * dot(rb) % R == dot(rc)
     # ---- trapdoor and QAP evaluations at tau
     tau, alpha, beta, gamma, delta = (1 + rng.below(R - 1) for _ in range(5))
     S = N.bit_length()                       # log2(2N)
@@ -149,9 +161,9 @@ def build(points, n_bits, n_bytes, n_prod, seed=1):
     zkey = b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(secs)
     vk = dict(alpha1=bytes(hdr1[0]), beta2=bytes(hdr2[0]), gamma2=bytes(hdr2[1]), delta2=bytes(hdr2[2]),
               ic=[bytes(pic[i]) for i in range(n_public + 1)])
-    wit = np.frombuffer(b"".join(pm.limbs(x) for x in w), dtype=np.uint8).reshape(n_vars, 32).copy()
-    return dict(zkey=zkey, vk=vk, witness=wit, public=[w[1]], n_vars=n_vars, n_public=n_public, domain=N,
-                n_coefs=len(coefs))
+    return dict(zkey=zkey, vk=vk, witness=witness_bytes(w), public=[w[1]], n_vars=n_vars, n_public=n_public, domain=N,
+                n_coefs=len(coefs),
+                new_witness=lambda wseed: (lambda ww: (witness_bytes(ww), [ww[1]]))(make_witness(wseed)))
 
 
 def oracle_points(group, scalars):
