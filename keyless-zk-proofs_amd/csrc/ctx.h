@@ -144,6 +144,8 @@ struct k16_ctx {
     unsigned    acc_grid_cap  = 0; // K16_ACC_GRID: at most this many (persistent, grid-stride) accumulate workgroups
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
+    unsigned    n_cu = 256;       // compute units of the device (persistent grids are sized from it)
+    unsigned    ntt_grid_cap = 0; // K16_NTT_GRID: workgroups of an NTT pass (0: all that are resident at once)
 };
 
 // Lane streams are created on first use: ROCm multiplexes a process's streams onto 4 hardware queues by default
@@ -187,5 +189,6 @@ struct k16_stat_scope {
 int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out);
 // packed9: bit 0 = data is in the packed R' domain, bit 1 = input already bit-reversed, bit 2 = skip the inverse tail
 int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st, int packed9);
-int k16_ntt_tail_shift_bitrev(k16_ctx* ctx, const k16::Fr* src, k16::Fr* dst, uint64_t n, k16_ntt_table* tab,
-                              uint32_t stride_log, hipStream_t st);
+int k16_ntt_coset_chain(k16_ctx* ctx, k16::Fr* const* src, k16::Fr* const* dst, int count, uint64_t n, k16_ntt_table* tab,
+                        const k16::Fr* shift9, hipStream_t st);
+int k16_ntt_build_coset_shift(k16_ctx* ctx, k16_ntt_table* tab, uint64_t n, k16::Fr** out, hipStream_t st);

@@ -112,14 +112,28 @@ __device__ __forceinline__ void st_r9(Fr* p, const Fr9& v)
     fr9_store(w.v, v);
     st_fr(p, w);
 }
-template <bool CONV_IN, bool CONV_OUT>
-__global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr* __restrict__ roots9, uint32_t s0,
-                                                   uint32_t K, uint32_t TL, uint32_t S)
+// Up to three polynomials per launch (blockIdx.y): the prover's a / b / c chains are independent, and a pass of one
+// polynomial spends a quarter of its time filling and draining the chip (all resident workgroups load before any computes).
+struct NttPtrs {
+    Fr* src[3];
+    Fr* dst[3]; // TAIL only
+};
+// TAIL (the last pass of the prover's inverse transforms): instead of storing the tile in place, apply what the
+// reference does between the inverse and the coset-forward transform -- iNTT tail (fft.cpp:226-245: y[i] = X[(n-i) mod n] *
+// 2^-k), coset shift (y[i] *= g^i, groth16.cpp:196-205) and the bit reversal that opens the forward transform (fft.cpp:170-189):
+//     dst[bitrev(i)] = X[(n - i) mod n] * shift9[i],   shift9[i] = 2^-k * g^i  (one table, one multiplication)
+// The tile is read mid-major for that store (the mid bits are the LOW bits of bitrev(i): runs of 2^K * 32 bytes in dst),
+// with one element of padding per tile row so that the LDS reads stay conflict-free.
+template <bool CONV_IN, bool CONV_OUT, bool TAIL>
+__global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restrict__ roots9, uint32_t s0, uint32_t K,
+                                                   uint32_t TL, uint32_t S, uint32_t logn, const Fr* __restrict__ shift9)
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     extern __shared__ uint4 ntt_lds[];
     Fr9*           tile  = reinterpret_cast<Fr9*>(ntt_lds);
+    Fr* __restrict__ a   = pp.src[blockIdx.y];
     const uint32_t T     = 1u << TL;
+    const uint32_t RS    = (TAIL && TL) ? T + 1 : T; // tile row stride in elements
     const uint32_t telem = T << K;
     const uint32_t lo_tiles = (1u << s0) >> TL;
     const uint32_t hi    = blockIdx.x / lo_tiles;
@@ -128,12 +142,13 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
     for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {
         const uint32_t mid = e >> TL, tl = e & (T - 1);
         const Fr*      src = &a[base + ((size_t)mid << s0) + tl];
-        tile[e] = CONV_IN ? fr9_from_fr(ld_fr(src)) : ld_r9(src);
+        tile[mid * RS + tl] = CONV_IN ? fr9_from_fr(ld_fr(src)) : ld_r9(src);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     // Lazy reduction inside the pass: tile values enter < 2r and grow by 2r per stage (u + t, u - t + 2r with t < 2r
-    // fresh from the multiply), so after K <= 12 stages they are < 26r < 2^259 -- within the 9 x 29-bit limbs and within
+    // fresh from the multiply; the twiddle-free first two stages of a transform end < 8r), so after K <= 11 stages they
+    // are < 26r < 2^259 -- within the 9 x 29-bit limbs and within
     // the multiply's operand bound (2 * 26 <= 128); one fred9 at the store brings them back.
     const uint32_t nbf = telem >> 1;
     uint32_t       t   = 1;
@@ -144,11 +159,11 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
             const uint32_t ml = mm & (half - 1), mh = mm >> (t - 1);
             const uint32_t m0 = (mh << t) + ml, m1 = m0 + half;
             const size_t   j  = ((size_t)ml << s0) + lo0 + tl;
-            Fr9            x1 = tile[(m1 << TL) + tl];
-            Fr9            u  = tile[(m0 << TL) + tl];
+            Fr9            x1 = tile[m1 * RS + tl];
+            Fr9            u  = tile[m0 * RS + tl];
             Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_r9(&roots9[j << (S - s0 - t)]), x1); // s0 == 0: the twiddle is 1
-            tile[(m0 << TL) + tl] = fadd9(u, tt);
-            tile[(m1 << TL) + tl] = fsub9_t<Fr9C, 2>(u, tt);
+            tile[m0 * RS + tl] = fadd9(u, tt);
+            tile[m1 * RS + tl] = fsub9_t<Fr9C, 2>(u, tt);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -164,7 +179,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
             const uint32_t tl = g & (T - 1), mm = g >> TL;
             const uint32_t ml = mm & (h - 1), mh = mm >> (t - 1);
             const uint32_t m0 = (mh << (t + 1)) + ml;
-            const uint32_t i0 = (m0 << TL) + tl, dh = h << TL;
+            const uint32_t i0 = m0 * RS + tl, dh = h * RS;
             const size_t   ja = ((size_t)ml << s0) + lo0 + tl;         // twiddle index of stage t, and of (m0, m0+2h) in t+1
             const size_t   jb = ((size_t)(ml + h) << s0) + lo0 + tl;   // (m0+h, m0+3h) in stage t+1
             Fr9            x0 = tile[i0], x1 = tile[i0 + dh], x2 = tile[i0 + 2 * dh], x3 = tile[i0 + 3 * dh];
@@ -183,21 +198,43 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(Fr* __restrict__ a, const Fr*
             Fr9 q2 = unit ? a2 : frmul9(ld_r9(&roots9[ja << (S - s0 - t - 1)]), a2);
             Fr9 q3 = frmul9(ld_r9(&roots9[jb << (S - s0 - t - 1)]), a3);
             tile[i0]          = fadd9(a0, q2);
-            tile[i0 + 2 * dh] = fsub9_t<Fr9C, 2>(a0, q2);
+            // unit: q2 = a2 = x2 + x3 is not fresh from a multiplication -- up to 4r, so the offset must be 4r (with 2r the
+            // difference goes negative when x2, x3 >= r and x0 + x1 is small: about once per 10^3 proofs of 2^21 with
+            // inputs < 1.006 r, every proof with inputs < 1.07 r)
+            tile[i0 + 2 * dh] = unit ? fsub9_t<Fr9C, 4>(a0, q2) : fsub9_t<Fr9C, 2>(a0, q2);
             tile[i0 + dh]     = fadd9(a1, q3);
             tile[i0 + 3 * dh] = fsub9_t<Fr9C, 2>(a1, q3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    if (TAIL) {
+        Fr* __restrict__ d    = pp.dst[blockIdx.y];
+        const uint32_t   nm1  = (1u << logn) - 1;
+        for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {
+            const uint32_t mid = e & ((1u << K) - 1), tl = e >> K;
+            const uint32_t f   = (uint32_t)base + (mid << s0) + tl;
+            const uint32_t i   = (0u - f) & nm1;                       // (n - f) mod n
+            const uint32_t to  = logn ? (__brev(i) >> (32 - logn)) : 0u;
+            st_r9(&d[to], frmul9(tile[mid * RS + tl], ld_r9(&shift9[i]))); // 26 * 2 <= 128: < 2r
+        }
+        return;
+    }
     for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {
         const uint32_t mid = e >> TL, tl = e & (T - 1);
         Fr*            dst = &a[base + ((size_t)mid << s0) + tl];
         if (CONV_OUT)
-            st_fr(dst, fr9_to_fr(tile[e]));             // multiply by 2^256 / 2^261: any bound <= 64r is fine
+            st_fr(dst, fr9_to_fr(tile[mid * RS + tl]));             // multiply by 2^256 / 2^261: any bound <= 64r is fine
         else
-            st_r9(dst, fred9_t<Fr9C>(tile[e]));         // < r (1 + 2^-17): fits the 32-byte packed form
+            st_r9(dst, fred9_t<Fr9C>(tile[mid * RS + tl]));         // < r (1 + 2^-17): fits the 32-byte packed form
     }
+}
+// shift9[i] = 2^-logn * g^i, g the primitive 2^(logn+1)-th root: the factor between the inverse and the coset-forward transform
+__global__ void __launch_bounds__(256) k_build_shift9(Fr* __restrict__ shift9, const Fr* __restrict__ roots9, uint32_t n,
+                                                      uint32_t stride_log, Fr9 scale)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_r9(&shift9[i], fred9_t<Fr9C>(frmul9(ld_r9(&roots9[(size_t)i << stride_log]), scale)));
 }
 // fft.cpp:226-245 on packed R' data
 __global__ void __launch_bounds__(256) k_inv_tail9(Fr* __restrict__ a, uint32_t logn, Fr9 scale)
@@ -285,6 +322,38 @@ int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out)
     return K16_OK;
 }
 
+// the fused passes of one transform over `count` polynomials; tail_dst != nullptr: the last pass stores through the TAIL path
+static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn, k16_ntt_table* tab, bool packed9,
+                       Fr* const* tail_dst, const Fr* shift9, hipStream_t st)
+{
+    NttPtrs pp = {};
+    for (int i = 0; i < count; i++) {
+        pp.src[i] = polys[i];
+        pp.dst[i] = tail_dst ? tail_dst[i] : nullptr;
+    }
+    const uint64_t n  = 1ull << logn;
+    uint32_t       s0 = 0;
+    while (s0 < logn) {
+        const uint32_t TL = s0 < 4 ? s0 : 4;                      // T = min(2^s0, 16) lo values per tile
+        const uint32_t K  = std::min<uint32_t>(logn - s0, 10 - TL); // <= 1024 elements per tile
+        const bool     first = s0 == 0, last = s0 + K == logn;
+        const bool     cin = !packed9 && first, cout = !packed9 && last, tail = tail_dst && last;
+        const dim3     grid((unsigned)(n >> (K + TL)), (unsigned)count);
+        const size_t   lds = (size_t)(((tail && TL) ? (1u << TL) + 1 : (1u << TL)) << K) * sizeof(Fr9);
+        if (tail)
+            hipLaunchKernelGGL((k_ntt_pass9<false, false, true>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+        else if (cin && cout)
+            hipLaunchKernelGGL((k_ntt_pass9<true, true, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+        else if (cin)
+            hipLaunchKernelGGL((k_ntt_pass9<true, false, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+        else if (cout)
+            hipLaunchKernelGGL((k_ntt_pass9<false, true, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+        else
+            hipLaunchKernelGGL((k_ntt_pass9<false, false, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+        s0 += K;
+    }
+}
+
 int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st, int packed9)
 {
     if (!st) st = ctx->stream;
@@ -303,25 +372,8 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
                 hipLaunchKernelGGL(k_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, d_a, tab->roots, logn,
                                    s, tab->s);
         } else {
-            uint32_t s0 = 0;
-            while (s0 < logn) {
-                const uint32_t TL = s0 < 4 ? s0 : 4;                      // T = min(2^s0, 16) lo values per tile
-                const uint32_t K  = std::min<uint32_t>(logn - s0, 10 - TL); // <= 1024 elements per tile
-                const uint32_t telem = 1u << (K + TL);
-                const bool     first = s0 == 0, last = s0 + K == logn;
-                const bool     cin = !packed9 && first, cout = !packed9 && last;
-                const dim3     grid((unsigned)(n >> (K + TL)));
-                const size_t   lds = telem * sizeof(Fr9);
-                if (cin && cout)
-                    hipLaunchKernelGGL((k_ntt_pass9<true, true>), grid, dim3(256), lds, st, d_a, tab->roots9, s0, K, TL, tab->s);
-                else if (cin)
-                    hipLaunchKernelGGL((k_ntt_pass9<true, false>), grid, dim3(256), lds, st, d_a, tab->roots9, s0, K, TL, tab->s);
-                else if (cout)
-                    hipLaunchKernelGGL((k_ntt_pass9<false, true>), grid, dim3(256), lds, st, d_a, tab->roots9, s0, K, TL, tab->s);
-                else
-                    hipLaunchKernelGGL((k_ntt_pass9<false, false>), grid, dim3(256), lds, st, d_a, tab->roots9, s0, K, TL, tab->s);
-                s0 += K;
-            }
+            Fr* one[1] = {d_a};
+            ntt_passes(ctx, one, 1, logn, tab, packed9 != 0, nullptr, nullptr, st);
         }
     }
     if (inverse && !skip_tail) {
@@ -339,28 +391,39 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
     return K16_OK;
 }
 
-// Prover-internal fusion of three permutation / scaling passes between the inverse and the forward transform
-// of the coset chain (groth16.cpp:172-262): iNTT tail (fft.cpp:226-245: y[i] = X[(n-i) mod n] * 2^-k), coset
-// shift (y[i] *= root(k+1, i)) and the bit reversal that opens the next forward transform, out of place:
-//     dst[bitrev(i)] = src[(n - i) mod n] * 2^-k * root(k+1, i)
-__global__ void __launch_bounds__(256) k_tail_shift_bitrev9(const Fr* __restrict__ src, Fr* __restrict__ dst, uint32_t logn,
-                                                            Fr9 scale, const Fr* __restrict__ roots9, uint32_t stride_log)
+// The prover's coset chain on `count` <= 3 polynomials at once (groth16.cpp:172-262: ifft, coset shift, fft per polynomial):
+// src[k] holds packed R' data in bit-reversed order (the SpMV writes it that way); the inverse passes run in place, their
+// last pass stores [tail, shift, bit reversal] into dst[k] (k_ntt_pass9<.., TAIL>), the forward passes run in place on dst[k].
+// shift9 comes from k16_ntt_build_coset_shift for this n.  src and dst must not overlap.
+int k16_ntt_coset_chain(k16_ctx* ctx, k16::Fr* const* src, k16::Fr* const* dst, int count, uint64_t n, k16_ntt_table* tab,
+                        const k16::Fr* shift9, hipStream_t st)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
-    const uint32_t n = 1u << logn;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t from = (n - i) & (n - 1);
-    Fr9            v    = frmul9(frmul9(ld_r9(&src[from]), scale), ld_r9(&roots9[(size_t)i << stride_log]));
-    const uint32_t to   = logn ? (__brev(i) >> (32 - logn)) : 0u;
-    st_r9(&dst[to], v);
+    if (count < 1 || count > 3 || n < 1 || (n & (n - 1)) || 2 * n > (1ull << tab->s)) {
+        ctx->err = "ntt: coset chain needs 1-3 polynomials of a power-of-two size within the table";
+        return K16_ERR_ARG;
+    }
+    const uint32_t logn = ilog2_u64(n);
+    if (logn == 0) { // one point: every step of the chain is the identity
+        for (int k = 0; k < count; k++) K16_HIP(ctx, hipMemcpyAsync(dst[k], src[k], sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        return K16_OK;
+    }
+    k16_stat_scope ss(ctx, "ntt", st);
+    ntt_passes(ctx, src, count, logn, tab, true, dst, shift9, st);
+    ntt_passes(ctx, dst, count, logn, tab, true, nullptr, nullptr, st);
+    K16_HIP(ctx, hipGetLastError());
+    return K16_OK;
 }
-int k16_ntt_tail_shift_bitrev(k16_ctx* ctx, const k16::Fr* src, k16::Fr* dst, uint64_t n, k16_ntt_table* tab,
-                              uint32_t stride_log, hipStream_t st)
+
+int k16_ntt_build_coset_shift(k16_ctx* ctx, k16_ntt_table* tab, uint64_t n, k16::Fr** out, hipStream_t st)
 {
     const uint32_t logn = ilog2_u64(n);
-    hipLaunchKernelGGL(k_tail_shift_bitrev9, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, logn,
-                       tab->pow2inv9[logn], tab->roots9, stride_log);
+    if (n < 1 || (n & (n - 1)) || logn + 1 > tab->s) {
+        ctx->err = "ntt: coset shift table needs the roots of twice the domain";
+        return K16_ERR_ARG;
+    }
+    K16_HIP(ctx, hipMalloc((void**)out, (size_t)n * sizeof(Fr)));
+    hipLaunchKernelGGL(k_build_shift9, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st ? st : ctx->stream, *out, tab->roots9,
+                       (uint32_t)n, tab->s - logn - 1, tab->pow2inv9[logn]);
     K16_HIP(ctx, hipGetLastError());
     return K16_OK;
 }

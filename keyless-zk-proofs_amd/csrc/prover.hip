@@ -241,7 +241,8 @@ struct k16_prover {
     uint32_t *d_rowptr = nullptr, *d_wire = nullptr;
     Fr*       d_coef  = nullptr;
     // per-proof buffers
-    Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t = nullptr;
+    Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t[3] = {nullptr, nullptr, nullptr};
+    Fr* d_shift9 = nullptr; // 2^-k * g^i: between the inverse and the coset-forward transform (k16_ntt_build_coset_shift)
     k16_ntt_table* ntt = nullptr;
     hipStream_t    st2 = nullptr;          // polynomial chain (SpMV, NTTs) runs beside the witness MSMs
     hipEvent_t     ev_w = nullptr, ev_h = nullptr;
@@ -252,7 +253,7 @@ static void prover_free(k16_prover* p)
 {
     if (!p) return;
     void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_Htab, p->d_B2, p->d_rowptr, p->d_wire, p->d_coef,
-                    p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t};
+                    p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t[0], p->d_t[1], p->d_t[2], p->d_shift9};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->st2) (void)hipStreamDestroy(p->st2);
@@ -395,7 +396,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_a, (size_t)N * 32), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_b, (size_t)N * 32), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_c, (size_t)N * 32), p);
-    K16_HIP_P(ctx, hipMalloc((void**)&p->d_t, (size_t)N * 32), p);
+    for (int k = 0; k < 3; k++) K16_HIP_P(ctx, hipMalloc((void**)&p->d_t[k], (size_t)N * 32), p);
     hipStream_t st = ctx->stream;
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_A, bv.sec[5].p, nv * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_B1, bv.sec[6].p, nv * 64, hipMemcpyHostToDevice, st), p);
@@ -432,6 +433,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipStreamSynchronize(st), p);
     // FFT table for 2 * domainSize (groth16.hpp:96)
     rc = k16_ntt_get_table(ctx, 2ull * N, &p->ntt);
+    if (!rc) rc = k16_ntt_build_coset_shift(ctx, p->ntt, N, &p->d_shift9, st);
     if (rc) {
         prover_free(p);
         return rc;
@@ -567,19 +569,13 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     hipLaunchKernelGGL(k_spmv, dim3((2 * N + 255) / 256), dim3(256), 0, s2, p->d_rowptr, p->d_wire, p->d_coef,
                        p->d_wtns, p->d_a, p->d_b, N, p->logN);
     hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N); // elementwise: same permutation
-    // x -> iNTT passes (input already bit-reversed, tail deferred) -> [tail, coset shift, bit reversal] fused and
-    // out of place -> NTT passes.  Buffers rotate: a -> t, b -> a, c -> b.
+    // a, b, c together: iNTT passes in place (input already bit-reversed; the last pass stores [tail, coset shift, bit
+    // reversal] into d_t[k]), then the forward passes in place on d_t[k] -- six launches for the six transforms
     Fr* src[3] = {p->d_a, p->d_b, p->d_c};
-    Fr* dst[3] = {p->d_t, p->d_a, p->d_b};
-    for (int k = 0; k < 3; k++) {
-        if ((rc = k16_ntt_enqueue(ctx, src[k], N, p->ntt, 1, s2, 1 | 2 | 4))) return rc;
-        if ((rc = k16_ntt_tail_shift_bitrev(ctx, src[k], dst[k], N, p->ntt, p->ntt->s - p->logN - 1, s2))) return rc;
-        if ((rc = k16_ntt_enqueue(ctx, dst[k], N, p->ntt, 0, s2, 1 | 2))) return rc;
-    }
-    // A in d_t, B in d_a, C in d_b; the H scalars go to d_c (free now), which then becomes the prover's "a" buffer
-    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_t, p->d_a, p->d_b, N);
+    if ((rc = k16_ntt_coset_chain(ctx, src, p->d_t, 3, N, p->ntt, p->d_shift9, s2))) return rc;
+    // the H scalars go to d_a (free since the inverse transform's last pass)
+    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_t[0], p->d_t[1], p->d_t[2], N);
     K16_HIP(ctx, hipGetLastError());
-    std::swap(p->d_a, p->d_c);
     K16_HIP(ctx, hipEventRecord(p->ev_h, s2));
     ht("chain enqueued");
 

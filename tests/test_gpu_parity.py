@@ -227,7 +227,8 @@ def test_toy_proof_bit_exact(ctx, toy_paths):
     p.close()
 
 
-@pytest.mark.parametrize("shape", [(3000, 2, 4096, 9000), (40000, 1, 1 << 16, 150000), (140000, 1, 1 << 18, 400000)])
+@pytest.mark.parametrize("shape", [(3000, 2, 4096, 9000), (20000, 1, 1 << 15, 60000), (40000, 1, 1 << 16, 150000),
+                                   (70000, 1, 1 << 17, 200000), (140000, 1, 1 << 18, 400000)])
 def test_synthetic_circuit_proof_bit_exact(ctx, tmp_path, shape):
     """Non-toy prove(): random circuit of the given (nVars, nPublic, domainSize, nCoefs); the HIP proof JSON and
     the H scalars must equal the oracle's byte for byte (same witness, same injected r, s)."""
@@ -658,6 +659,41 @@ def test_ntt_forward_and_inverse_2p21_vs_oracle(ctx):
         got = ctx.ntt(a, max_domain=2 * n, inverse=inverse)
         want = ol.ntt(a, max_domain=2 * n, inverse=inverse)
         assert np.array_equal(got, want), inverse
+
+
+def test_ntt_first_stage_pair_with_representatives_above_r(ctx):
+    """Regression: the twiddle-free first two stages of a transform subtract a2 = x2 + x3, which is not fresh from a
+    multiplication.  The kernels keep values as representatives in [0, 2r); when x2 and x3 are both >= r and x0 + x1 is
+    small, a0 - a2 + 2r went negative (the offset has to be 4r there).  Rare with random data (about one proof in 10^3 at
+    2^21), so the inputs are built for it: words whose radix-2^29 Montgomery representative (bn254_fq9.h fmul9_t:
+    (X * K_IN + m r) / 2^261) is >= r at the third and fourth element of a quad, zeros at the first two."""
+    logn = 12
+    n = 1 << logn
+    R9, k_in = 1 << 261, pow(2, 266, pm.R)
+    rinv = pow(pm.R, -1, R9)
+
+    def rep(x):
+        t = x * k_in
+        return (t + ((-t * rinv) % R9) * pm.R) >> 261
+
+    rng = pm.SplitMix64(4242)
+    above = []
+    while len(above) < 6:
+        x = rng.below(pm.R)
+        if rep(x) >= pm.R:
+            above.append(x)
+    rs = np.random.RandomState(17)
+    a = rs.randint(0, 2 ** 63, size=(n, 4)).astype(np.uint64)
+    a[:, 3] &= (1 << 60) - 1
+    brev = lambda v: int(format(v, "0%db" % logn)[::-1], 2)
+    for k, q in enumerate((0, 3, 700)):
+        pos = [brev(4 * q + j) for j in range(4)]      # the quad's elements in natural order
+        a[pos[0]] = 0
+        a[pos[1]] = 0
+        for j in (2, 3):
+            a[pos[j]] = np.frombuffer(pm.limbs(above[2 * k + j - 2]), dtype=np.uint64)
+    for inverse in (False, True):
+        assert np.array_equal(ctx.ntt(a, max_domain=2 * n, inverse=inverse), ol.ntt(a, max_domain=2 * n, inverse=inverse)), inverse
 
 
 @pytest.mark.parametrize("kind", ["uniform", "witness"])
