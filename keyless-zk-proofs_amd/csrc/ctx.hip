@@ -23,6 +23,13 @@ int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes)
     return K16_OK;
 }
 
+// ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  One prover uses exactly four
+// streams (three MSM lanes + the polynomial chain); a pool of provers on one GPU (K16_DEVICES=0,0,0) or a prover beside RCCL
+// needs more, or streams of different provers serialise behind each other: 175 -> 194 proofs/s for three provers sharing an
+// MI355X (profiles/r02).  The HIP runtime reads the variable when it initialises (first HIP call), after this library's
+// constructors have run; a value set by the user wins.
+__attribute__((constructor)) static void k16_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int k16_ctx_create(int device, k16_ctx** out)
 {
     if (!out) return K16_ERR_ARG;
