@@ -125,23 +125,61 @@ __device__ __forceinline__ void st_r9(Fr* p, const Fr9& v)
     fr9_store(w.v, v);
     st_fr(p, w);
 }
-// groth16.cpp:137-156 : ab[c] += wtns[s] (x) coef.  The zkey's coefficient list is regrouped once at
-// load time into CSR rows (matrix m, constraint c), so each lane owns one output element and no
-// 256-bit atomics / spinlocks are needed.  Field addition is exact, so the summation order is free.
-__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ wire,
+// groth16.cpp:137-156 : ab[c] += wtns[s] (x) coef.  The zkey's coefficient list is regrouped once at load time into rows
+// (matrix m, constraint c), so each output element has one owner and no 256-bit atomics / spinlocks are needed.  Field
+// addition is exact, so the summation order is free.  Layout (k16_prover_create): rows of up to SPMV_LONG entries are
+// sorted by length and packed 64 to a SLICE, entry k of lane l at slice.off + 64 k + l -- a wave reads 2 KB of
+// coefficients and 256 B of wire indices per step, and all its lanes loop the same number of times; longer rows (a circom
+// Num2Bits or a big linear combination: hundreds to thousands of entries) get a whole wave each, lanes striding over the
+// row's contiguous entries, and a butterfly reduction.  Rows land at their bit-reversed position: the inverse transforms
+// that follow skip their own reversal.
+constexpr uint32_t SPMV_LONG = 64;
+struct SpmvSlice {
+    uint32_t off, len; // first entry, entries per lane
+};
+struct SpmvLong {
+    uint32_t row, off, len;
+};
+__device__ __forceinline__ void spmv_store(Fr* __restrict__ a, Fr* __restrict__ b, uint32_t row, uint32_t N, uint32_t logN,
+                                           const Fr9& acc)
+{
+    const uint32_t r   = row < N ? row : row - N;
+    const uint32_t pos = logN ? (__brev(r) >> (32 - logN)) : 0u;
+    st_r9(row < N ? &a[pos] : &b[pos], acc);
+}
+__global__ void __launch_bounds__(256) k_spmv(const SpmvSlice* __restrict__ slices, uint32_t n_slices,
+                                              const uint32_t* __restrict__ row_of, const SpmvLong* __restrict__ longs,
+                                              uint32_t n_long, const uint32_t* __restrict__ wire,
                                               const Fr* __restrict__ coef9, const Fr* __restrict__ wtns,
                                               Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N, uint32_t logN)
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * N) return;
-    uint32_t lo = row_ptr[t], hi = row_ptr[t + 1];
-    Fr9      acc = fq9_zero();
-    for (uint32_t k = lo; k < hi; k++) acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[k]]), ld_r9(&coef9[k])));
-    // rows are stored at their bit-reversed position: the inverse transforms that follow skip their own reversal
-    const uint32_t row = t < N ? t : t - N;
-    const uint32_t pos = logN ? (__brev(row) >> (32 - logN)) : 0u;
-    st_r9(t < N ? &a[pos] : &b[pos], acc);
+    const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    Fr9            acc = fq9_zero();
+    if (w < n_slices) {
+        const SpmvSlice sl = slices[w];
+        for (uint32_t k = 0; k < sl.len; k++) {
+            const uint32_t e = sl.off + (k << 6) + lane; // padding entries: wire 0, coefficient 0
+            acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[e]]), ld_r9(&coef9[e])));
+        }
+        const uint32_t row = row_of[(w << 6) + lane];
+        if (row != 0xffffffffu) spmv_store(a, b, row, N, logN, acc);
+        return;
+    }
+    if (w - n_slices >= n_long) return;
+    const SpmvLong L = longs[w - n_slices];
+    for (uint32_t k = lane; k < L.len; k += 64) {
+        const uint32_t e = L.off + k;
+        acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[e]]), ld_r9(&coef9[e])));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        Fr9 o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.l[i] = (uint32_t)__shfl_xor((int)acc.l[i], d, 64);
+        acc = fradd9(acc, o);
+    }
+    if (lane == 0) spmv_store(a, b, L.row, N, logN, acc);
 }
 // groth16.cpp:160-167
 __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __restrict__ a, const Fr* __restrict__ b,
@@ -238,8 +276,12 @@ struct k16_prover {
     G1Aff *   d_A = nullptr, *d_B1 = nullptr, *d_C = nullptr, *d_H = nullptr;
     G1Aff*    d_Htab = nullptr; // fixed-base window tables of the H points (k16_msm_fixed_base_prepare), when available
     G2Aff*    d_B2    = nullptr;
-    uint32_t *d_rowptr = nullptr, *d_wire = nullptr;
-    Fr*       d_coef  = nullptr;
+    // constraint matrices A | B as length-sorted slices + long rows (see k_spmv)
+    SpmvSlice* d_slices = nullptr;
+    SpmvLong*  d_longs  = nullptr;
+    uint32_t * d_rowof = nullptr, *d_wire = nullptr;
+    Fr*        d_coef  = nullptr;
+    uint32_t   n_slices = 0, n_long = 0;
     // per-proof buffers
     Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t[3] = {nullptr, nullptr, nullptr};
     Fr* d_shift9 = nullptr; // 2^-k * g^i: between the inverse and the coset-forward transform (k16_ntt_build_coset_shift)
@@ -252,7 +294,7 @@ struct k16_prover {
 static void prover_free(k16_prover* p)
 {
     if (!p) return;
-    void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_Htab, p->d_B2, p->d_rowptr, p->d_wire, p->d_coef,
+    void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_Htab, p->d_B2, p->d_slices, p->d_longs, p->d_rowof, p->d_wire, p->d_coef,
                     p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t[0], p->d_t[1], p->d_t[2], p->d_shift9};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -345,9 +387,10 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         return K16_ERR_FORMAT;
     }
 
-    // regroup coefficients into CSR rows: row id = m * N + c   (Coef layout groth16.hpp:33-42, data at +4)
+    // regroup coefficients into rows: row id = m * N + c   (Coef layout groth16.hpp:33-42, data at +4)
     const uint8_t*        cf = bv.sec[4].p + 4;
-    std::vector<uint32_t> rowptr(2 * (size_t)N + 2, 0);
+    const size_t          n_rows = 2 * (size_t)N;
+    std::vector<uint32_t> len(n_rows, 0);
     for (uint64_t i = 0; i < p->n_coefs; i++) {
         uint32_t m, c, s;
         memcpy(&m, cf + i * 44, 4);
@@ -358,26 +401,76 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
             delete p;
             return K16_ERR_FORMAT;
         }
-        uint32_t row = (m == 0 ? 0 : N) + c; // groth16.cpp:147 : m == 0 -> a, else b
-        rowptr[row + 1]++;
+        len[(m == 0 ? 0 : N) + c]++; // groth16.cpp:147 : m == 0 -> a, else b
     }
-    for (size_t i = 0; i < 2 * (size_t)N; i++) rowptr[i + 1] += rowptr[i];
-    std::vector<uint32_t> fill(rowptr.begin(), rowptr.end() - 1);
-    std::vector<uint32_t> wire(p->n_coefs ? p->n_coefs : 1);
-    std::vector<uint8_t>  vals((p->n_coefs ? p->n_coefs : 1) * 32);
+    // short rows by length (counting sort, longest first so that the empty rows form the tail), 64 per slice
+    std::vector<uint32_t> by_len(SPMV_LONG + 2, 0);
+    std::vector<SpmvLong> longs;
+    for (size_t r = 0; r < n_rows; r++) {
+        if (len[r] > SPMV_LONG)
+            longs.push_back({(uint32_t)r, 0, len[r]});
+        else
+            by_len[SPMV_LONG - len[r] + 1]++;
+    }
+    for (size_t l = 0; l <= SPMV_LONG; l++) by_len[l + 1] += by_len[l];
+    const size_t          n_short = by_len[SPMV_LONG + 1];
+    const size_t          n_slices = (n_short + 63) / 64;
+    std::vector<uint32_t> row_of(std::max<size_t>(n_slices * 64, 1), 0xffffffffu);
+    std::vector<uint32_t> slot_of(n_rows, 0); // short row -> position in the sorted order
+    {
+        std::vector<uint32_t> cur(by_len.begin(), by_len.end() - 1);
+        for (size_t r = 0; r < n_rows; r++)
+            if (len[r] <= SPMV_LONG) {
+                const uint32_t q = cur[SPMV_LONG - len[r]]++;
+                row_of[q]        = (uint32_t)r;
+                slot_of[r]       = q;
+            }
+    }
+    std::vector<SpmvSlice> slices(std::max<size_t>(n_slices, 1), SpmvSlice{0, 0});
+    uint64_t               total = 0;
+    for (size_t sidx = 0; sidx < n_slices; sidx++) {
+        const uint32_t first = row_of[sidx * 64];          // the longest row of the slice
+        slices[sidx]         = {(uint32_t)total, len[first]};
+        total += (uint64_t)len[first] * 64;
+    }
+    std::vector<uint32_t> long_of(longs.empty() ? 0 : n_rows, 0);
+    for (size_t k = 0; k < longs.size(); k++) {
+        longs[k].off          = (uint32_t)total;
+        long_of[longs[k].row] = (uint32_t)k;
+        total += longs[k].len;
+    }
+    if (total >= (1ull << 32)) {
+        ctx->err = "zkey: too many coefficients for 32-bit entry offsets";
+        delete p;
+        return K16_ERR_FORMAT;
+    }
+    std::vector<uint32_t> wire(std::max<uint64_t>(total, 1), 0);
+    std::vector<uint8_t>  vals(std::max<uint64_t>(total, 1) * 32, 0); // padding: coefficient 0 (times wire 0)
+    std::vector<uint32_t> fill(n_rows, 0);
     for (uint64_t i = 0; i < p->n_coefs; i++) {
         uint32_t m, c, s;
         memcpy(&m, cf + i * 44, 4);
         memcpy(&c, cf + i * 44 + 4, 4);
         memcpy(&s, cf + i * 44 + 8, 4);
-        uint32_t pos = fill[(m == 0 ? 0 : N) + c]++;
-        wire[pos]    = s;
+        const uint32_t row = (m == 0 ? 0 : N) + c;
+        const uint32_t k   = fill[row]++;
+        size_t         pos;
+        if (len[row] > SPMV_LONG) {
+            pos = (size_t)longs[long_of[row]].off + k;
+        } else {
+            const uint32_t q = slot_of[row];
+            pos              = (size_t)slices[q >> 6].off + ((size_t)k << 6) + (q & 63);
+        }
+        wire[pos] = s;
         // stored value = coef * 2^512 mod r (canonical); the Fr9 kernels want coef * 2^522: ten modular doublings
         Fr cv;
         memcpy(cv.v, cf + i * 44 + 12, 32);
         for (int d = 0; d < 10; d++) cv = fdbl(cv);
-        memcpy(&vals[(size_t)pos * 32], cv.v, 32);
+        memcpy(&vals[pos * 32], cv.v, 32);
     }
+    p->n_slices = (uint32_t)n_slices;
+    p->n_long   = (uint32_t)longs.size();
+    if (longs.empty()) longs.push_back({0, 0, 0});
 
     K16_HIP_P(ctx, hipSetDevice(ctx->device), p);
     const size_t nv = p->n_vars, nc = p->n_vars - p->n_public - 1;
@@ -389,7 +482,9 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // MSM's bucket sort instead of sorting the same scalars, shifted by two, once more; (0,0) rows contribute nothing
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_C, std::max<size_t>(nv * 64, 64)), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_H, (size_t)N * 64), p);
-    K16_HIP_P(ctx, hipMalloc((void**)&p->d_rowptr, rowptr.size() * 4), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_slices, slices.size() * sizeof(SpmvSlice)), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_longs, longs.size() * sizeof(SpmvLong)), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_rowof, row_of.size() * 4), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_wire, wire.size() * 4), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_coef, vals.size()), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_wtns, nv * 32), p);
@@ -404,7 +499,9 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMemsetAsync(p->d_C, 0, (nv - nc) * 64, st), p);
     if (nc) K16_HIP_P(ctx, hipMemcpyAsync(p->d_C + (nv - nc), bv.sec[8].p, nc * 64, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_H, bv.sec[9].p, (size_t)N * 64, hipMemcpyHostToDevice, st), p);
-    K16_HIP_P(ctx, hipMemcpyAsync(p->d_rowptr, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_slices, slices.data(), slices.size() * sizeof(SpmvSlice), hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_longs, longs.data(), longs.size() * sizeof(SpmvLong), hipMemcpyHostToDevice, st), p);
+    K16_HIP_P(ctx, hipMemcpyAsync(p->d_rowof, row_of.data(), row_of.size() * 4, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_wire, wire.data(), wire.size() * 4, hipMemcpyHostToDevice, st), p);
     K16_HIP_P(ctx, hipMemcpyAsync(p->d_coef, vals.data(), vals.size(), hipMemcpyHostToDevice, st), p);
     // The H MSM has uniform 254-bit scalars and is the longest item of a proof: its static table gets precomputed window
@@ -566,8 +663,12 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     K16_HIP(ctx, hipEventRecord(p->ev_w, st));
     K16_HIP(ctx, hipStreamWaitEvent(s2, p->ev_w, 0));
     const unsigned gN = (N + 255) / 256;
-    hipLaunchKernelGGL(k_spmv, dim3((2 * N + 255) / 256), dim3(256), 0, s2, p->d_rowptr, p->d_wire, p->d_coef,
-                       p->d_wtns, p->d_a, p->d_b, N, p->logN);
+    {
+        const uint64_t waves = (uint64_t)p->n_slices + p->n_long;
+        if (waves)
+            hipLaunchKernelGGL(k_spmv, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, p->d_slices, p->n_slices, p->d_rowof,
+                               p->d_longs, p->n_long, p->d_wire, p->d_coef, p->d_wtns, p->d_a, p->d_b, N, p->logN);
+    }
     hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N); // elementwise: same permutation
     // a, b, c together: iNTT passes in place (input already bit-reversed; the last pass stores [tail, coset shift, bit
     // reversal] into d_t[k]), then the forward passes in place on d_t[k] -- six launches for the six transforms

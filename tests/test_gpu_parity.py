@@ -251,6 +251,27 @@ def test_synthetic_circuit_proof_bit_exact(ctx, tmp_path, shape):
     p.close()
 
 
+def test_proof_with_long_constraint_rows_bit_exact(ctx, tmp_path):
+    """Constraint rows far from the average length (RS/groth16.cpp:137-156 walks the coefficient list, so the reference
+    does not care): rows of 65, 200, 1000 and 5000 entries next to ~3 per row, rows of exactly 64 and 63, and an A / B
+    matrix whose other rows are mostly empty.  The device keeps rows of <= 64 entries in length-sorted slices and gives a
+    wave to each longer row (k_spmv)."""
+    import k16
+    import zkey_builder as zb
+    n_vars, N, n_coefs = 9000, 1 << 13, 30000
+    zk, wt = str(tmp_path / "l.zkey"), str(tmp_path / "l.wtns")
+    zb.build_zkey(zk, n_vars, 1, N, n_coefs, seed=21, long_rows=(65, 200, 1000, 5000, 64, 63, 129))
+    zb.build_wtns(wt, n_vars, seed=22)
+    r, s = pm.limbs(pm.SplitMix64(5).below(pm.R)), pm.limbs(pm.SplitMix64(6).below(pm.R))
+    p = k16.Prover(ctx, zk)
+    got = p.prove_file(wt, r, s)
+    h_gpu = p.last_h()
+    want, h_ref = ol.prove_files(zk, wt, r, s, nthreads=8, want_h=True)
+    assert np.array_equal(h_gpu, h_ref)
+    assert got == want
+    p.close()
+
+
 def test_msm_g1_2p23_shard_closed_form(ctx):
     """BASELINE config 5 shard size (2^26 points over 8 GPUs = 2^23 per GPU): bases (off+i+1)*G generated on the
     device, scalars i+1, checked against the closed form sum (i+1)(off+i+1) * G; and the per-shard partials of two

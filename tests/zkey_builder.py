@@ -15,7 +15,9 @@ def _section(t, payload):
     return struct.pack("<IQ", t, len(payload)) + payload
 
 
-def build_zkey(path, n_vars, n_public, domain_size, n_coefs, seed=1, zero_frac=0.3):
+def build_zkey(path, n_vars, n_public, domain_size, n_coefs, seed=1, zero_frac=0.3, long_rows=()):
+    """long_rows: lengths of extra constraint rows of one matrix each (65 ... thousands of entries, as circom's Num2Bits or
+    a wide linear combination produce); their coefficients are part of n_coefs and keep the file sorted by constraint."""
     rs = np.random.RandomState(seed)
     g1 = ol.gen_points(ol.G1, 100, 6)          # alpha1, beta1, delta1 + spare
     g2 = ol.gen_points(ol.G2, 50, 3)           # beta2, gamma2, delta2
@@ -24,7 +26,15 @@ def build_zkey(path, n_vars, n_public, domain_size, n_coefs, seed=1, zero_frac=0
     hdr += bytes(g1[0]) + bytes(g1[1]) + bytes(g2[0]) + bytes(g2[1]) + bytes(g1[2]) + bytes(g2[2])
     # coefficients: (m, c, s, value * R^2 mod r), grouped by c then m as snarkjs writes them
     m = rs.randint(0, 2, size=n_coefs).astype(np.uint32)
-    c = np.sort(rs.randint(0, domain_size, size=n_coefs)).astype(np.uint32)
+    c = rs.randint(0, domain_size, size=n_coefs).astype(np.uint32)
+    at = 0
+    for k, ln in enumerate(long_rows):          # one (m, c) row gets ln entries
+        assert at + ln <= n_coefs
+        c[at:at + ln] = (k * 7919 + 5) % domain_size
+        m[at:at + ln] = k & 1
+        at += ln
+    order = np.argsort(c, kind="stable")
+    c, m = c[order], m[order]
     s = rs.randint(0, n_vars, size=n_coefs).astype(np.uint32)
     r2 = pow(pm.MONT, 2, pm.R)
     coefs = bytearray(struct.pack("<I", n_coefs))
