@@ -24,4 +24,11 @@ python3 bench.py --mode strong --total-log2n 26 --steps 3 --warmup 1 --proofs 0 
 python3 bench.py --gpus 2 --steps 2 --warmup 1 --proofs 0 > $O/bench_gpus2_on_1gpu_box.out 2>&1; echo "rc=$?" >> $O/bench_gpus2_on_1gpu_box.out
 # 7. verifier
 python3 tools/bench_verify.py > $O/verify.json 2> $O/verify.err
+# 8. BASELINE config 4 on one GPU: a wave of proofs of a valid synthetic key from a prover pool, one batched verification
+python3 tools/config4_wave.py --provers 3 --wave 96 > $O/config4_wave_1gpu.json 2> $O/config4_wave_1gpu.err
+# 9. kernel timeline of one proof, the isolated fixed-base H MSM, the NTT through the public entry point
+rocprofv3 --kernel-trace --output-format csv -d /tmp/k16_tl -- python3 tools/bench_proof.py --proofs 6 > /dev/null 2> $O/proof_timeline.err
+python3 tools/proof_timeline.py /tmp/k16_tl 2 > $O/proof_timeline.txt 2>> $O/proof_timeline.err
+python3 tools/fixed_base_timing.py 21 8 > $O/fixed_base_h_msm.log 2>&1
+python3 tools/ntt_timing.py 21 30 > $O/ntt_2p21.log 2>&1
 ls -la $O
