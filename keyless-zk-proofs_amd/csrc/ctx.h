@@ -185,7 +185,7 @@ struct k16_stat_scope {
     }
 };
 
-// host-side helpers implemented in msm.hip
+// host-side helpers implemented in ntt.hip
 int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out);
 // packed9: bit 0 = data is in the packed R' domain, bit 1 = input already bit-reversed, bit 2 = skip the inverse tail
 int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, int inverse, hipStream_t st, int packed9);
