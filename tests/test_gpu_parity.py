@@ -227,7 +227,8 @@ def test_toy_proof_bit_exact(ctx, toy_paths):
     p.close()
 
 
-@pytest.mark.parametrize("shape", [(3000, 2, 4096, 9000), (20000, 1, 1 << 15, 60000), (40000, 1, 1 << 16, 150000),
+@pytest.mark.parametrize("shape", [(6, 1, 1, 4), (8, 1, 2, 8), (30, 2, 8, 40), (300, 1, 1024, 900), (700, 1, 2048, 2000),
+                                   (3000, 2, 4096, 9000), (20000, 1, 1 << 15, 60000), (40000, 1, 1 << 16, 150000),
                                    (70000, 1, 1 << 17, 200000), (140000, 1, 1 << 18, 400000)])
 def test_synthetic_circuit_proof_bit_exact(ctx, tmp_path, shape):
     """Non-toy prove(): random circuit of the given (nVars, nPublic, domainSize, nCoefs); the HIP proof JSON and
