@@ -144,8 +144,6 @@ struct k16_ctx {
     unsigned    acc_grid_cap  = 0; // K16_ACC_GRID: at most this many (persistent, grid-stride) accumulate workgroups
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
-    unsigned    n_cu = 256;       // compute units of the device (persistent grids are sized from it)
-    unsigned    ntt_grid_cap = 0; // K16_NTT_GRID: workgroups of an NTT pass (0: all that are resident at once)
 };
 
 // Lane streams are created on first use: ROCm multiplexes a process's streams onto 4 hardware queues by default

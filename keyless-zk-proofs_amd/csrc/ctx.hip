@@ -50,11 +50,6 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (const char* e = getenv("K16_WSUM_MLOG_CAP")) c->wsum_mlog_cap = (unsigned)atoi(e);
     if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
     if (const char* e = getenv("K16_ACC_FENCE")) c->acc_fence_mode = atoi(e);
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cu = (unsigned)cus;
-    }
-    if (const char* e = getenv("K16_NTT_GRID")) c->ntt_grid_cap = (unsigned)std::max(0, atoi(e));
     if (const char* e = getenv("K16_ACC_GRID")) c->acc_grid_cap = (unsigned)std::max(0, atoi(e));
     if (const char* e = getenv("K16_ACC_LDS")) c->acc_lds_bytes = (unsigned)std::min(65536, std::max(0, atoi(e)));
     c->stream = c->lanes[0].stream;

@@ -25,4 +25,4 @@ ctx.stats_reset()
 for _ in range(reps):
     ctx.ntt_device(d, n)
 ctx.sync()
-print("log2n %d: %.1f us per transform (bit reversal + passes), K16_NTT_GRID=%s" % (logn, ctx.stats_get("ntt")[1] * 1e3 / reps, os.environ.get("K16_NTT_GRID", "auto")))
+print("log2n %d: %.1f us per transform (bit reversal + passes)" % (logn, ctx.stats_get("ntt")[1] * 1e3 / reps))
