@@ -465,7 +465,10 @@ K16_HD Xyzz9 xyzz9_from_canonical(const Xyzz<Fq>& p)
 // (value / 2^232 against p / 2^232 = 3171406.3): one 9-limb multiply-subtract, ~15 % of a multiply.
 // With the invariant in place the generic XYZZ formulas of bn254_curve.h apply unchanged (G2).
 // ------------------------------------------------------------------------------------------------
-// v < 16p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17))
+// v < 32p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17)):
+// v / 2^232 < (q + 1) * 3171407 and p / 2^232 > 3171406.3, so the remainder is below p (1 + (q + 1) * 2.2e-7) -- 7.1e-6 at
+// q = 31, against 2^-17 = 7.6e-6 (the NTT passes reduce tile values of up to 26 r with it); the reciprocal estimate is exact
+// or one less for top limbs below 2^27 (error t * 0.2 / 2^44 << 1), which the correction step settles.
 template <class C>
 K16_HD Fq9 fred9_t(const Fq9& v)
 {
