@@ -25,6 +25,7 @@
 #include <vector>
 #include "ctx.h"
 #include "bn254_fq9.h"
+#include "spmv_plan.h"
 
 using namespace k16;
 
@@ -133,13 +134,6 @@ __device__ __forceinline__ void st_r9(Fr* p, const Fr9& v)
 // Num2Bits or a big linear combination: hundreds to thousands of entries) get a whole wave each, lanes striding over the
 // row's contiguous entries, and a butterfly reduction.  Rows land at their bit-reversed position: the inverse transforms
 // that follow skip their own reversal.
-constexpr uint32_t SPMV_LONG = 64;
-struct SpmvSlice {
-    uint32_t off, len; // first entry, entries per lane
-};
-struct SpmvLong {
-    uint32_t row, off, len;
-};
 __device__ __forceinline__ void spmv_store(Fr* __restrict__ a, Fr* __restrict__ b, uint32_t row, uint32_t N, uint32_t logN,
                                            const Fr9& acc)
 {
@@ -387,90 +381,33 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         return K16_ERR_FORMAT;
     }
 
-    // regroup coefficients into rows: row id = m * N + c   (Coef layout groth16.hpp:33-42, data at +4)
-    const uint8_t*        cf = bv.sec[4].p + 4;
-    const size_t          n_rows = 2 * (size_t)N;
-    std::vector<uint32_t> len(n_rows, 0);
-    for (uint64_t i = 0; i < p->n_coefs; i++) {
-        uint32_t m, c, s;
-        memcpy(&m, cf + i * 44, 4);
-        memcpy(&c, cf + i * 44 + 4, 4);
-        memcpy(&s, cf + i * 44 + 8, 4);
-        if (c >= N || s >= p->n_vars) {
-            ctx->err = "zkey: coefficient index out of range";
-            delete p;
-            return K16_ERR_FORMAT;
-        }
-        len[(m == 0 ? 0 : N) + c]++; // groth16.cpp:147 : m == 0 -> a, else b
-    }
-    // short rows by length (counting sort, longest first so that the empty rows form the tail), 64 per slice
-    std::vector<uint32_t> by_len(SPMV_LONG + 2, 0);
-    std::vector<SpmvLong> longs;
-    for (size_t r = 0; r < n_rows; r++) {
-        if (len[r] > SPMV_LONG)
-            longs.push_back({(uint32_t)r, 0, len[r]});
-        else
-            by_len[SPMV_LONG - len[r] + 1]++;
-    }
-    for (size_t l = 0; l <= SPMV_LONG; l++) by_len[l + 1] += by_len[l];
-    const size_t          n_short = by_len[SPMV_LONG + 1];
-    const size_t          n_slices = (n_short + 63) / 64;
-    std::vector<uint32_t> row_of(std::max<size_t>(n_slices * 64, 1), 0xffffffffu);
-    std::vector<uint32_t> slot_of(n_rows, 0); // short row -> position in the sorted order
-    {
-        std::vector<uint32_t> cur(by_len.begin(), by_len.end() - 1);
-        for (size_t r = 0; r < n_rows; r++)
-            if (len[r] <= SPMV_LONG) {
-                const uint32_t q = cur[SPMV_LONG - len[r]]++;
-                row_of[q]        = (uint32_t)r;
-                slot_of[r]       = q;
-            }
-    }
-    std::vector<SpmvSlice> slices(std::max<size_t>(n_slices, 1), SpmvSlice{0, 0});
-    uint64_t               total = 0;
-    for (size_t sidx = 0; sidx < n_slices; sidx++) {
-        const uint32_t first = row_of[sidx * 64];          // the longest row of the slice
-        slices[sidx]         = {(uint32_t)total, len[first]};
-        total += (uint64_t)len[first] * 64;
-    }
-    std::vector<uint32_t> long_of(longs.empty() ? 0 : n_rows, 0);
-    for (size_t k = 0; k < longs.size(); k++) {
-        longs[k].off          = (uint32_t)total;
-        long_of[longs[k].row] = (uint32_t)k;
-        total += longs[k].len;
-    }
-    if (total >= (1ull << 32)) {
-        ctx->err = "zkey: too many coefficients for 32-bit entry offsets";
+    // regroup the coefficients into rows (spmv_plan.h): length-sorted 64-row slices + long rows
+    const uint8_t* cf = bv.sec[4].p + 4;
+    SpmvPlan       plan;
+    rc = spmv_plan_build(cf, p->n_coefs, N, p->n_vars, &plan);
+    if (rc) {
+        ctx->err = rc == -1 ? "zkey: coefficient index out of range" : "zkey: too many coefficients for 32-bit entry offsets";
         delete p;
         return K16_ERR_FORMAT;
     }
-    std::vector<uint32_t> wire(std::max<uint64_t>(total, 1), 0);
-    std::vector<uint8_t>  vals(std::max<uint64_t>(total, 1) * 32, 0); // padding: coefficient 0 (times wire 0)
-    std::vector<uint32_t> fill(n_rows, 0);
+    std::vector<SpmvSlice>& slices = plan.slices;
+    std::vector<SpmvLong>&  longs  = plan.longs;
+    std::vector<uint32_t>&  row_of = plan.row_of;
+    std::vector<uint32_t>   wire(std::max<uint64_t>(plan.n_entries, 1), 0);
+    std::vector<uint8_t>    vals(std::max<uint64_t>(plan.n_entries, 1) * 32, 0); // padding: coefficient 0 (times wire 0)
     for (uint64_t i = 0; i < p->n_coefs; i++) {
-        uint32_t m, c, s;
-        memcpy(&m, cf + i * 44, 4);
-        memcpy(&c, cf + i * 44 + 4, 4);
-        memcpy(&s, cf + i * 44 + 8, 4);
-        const uint32_t row = (m == 0 ? 0 : N) + c;
-        const uint32_t k   = fill[row]++;
-        size_t         pos;
-        if (len[row] > SPMV_LONG) {
-            pos = (size_t)longs[long_of[row]].off + k;
-        } else {
-            const uint32_t q = slot_of[row];
-            pos              = (size_t)slices[q >> 6].off + ((size_t)k << 6) + (q & 63);
-        }
-        wire[pos] = s;
+        const size_t pos = plan.pos_of[i];
+        uint32_t     sw;
+        memcpy(&sw, cf + i * 44 + 8, 4);
+        wire[pos] = sw;
         // stored value = coef * 2^512 mod r (canonical); the Fr9 kernels want coef * 2^522: ten modular doublings
         Fr cv;
         memcpy(cv.v, cf + i * 44 + 12, 32);
         for (int d = 0; d < 10; d++) cv = fdbl(cv);
         memcpy(&vals[pos * 32], cv.v, 32);
     }
-    p->n_slices = (uint32_t)n_slices;
-    p->n_long   = (uint32_t)longs.size();
-    if (longs.empty()) longs.push_back({0, 0, 0});
+    p->n_slices = plan.n_slices;
+    p->n_long   = plan.n_long;
 
     K16_HIP_P(ctx, hipSetDevice(ctx->device), p);
     const size_t nv = p->n_vars, nc = p->n_vars - p->n_public - 1;
