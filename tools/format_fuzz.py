@@ -81,7 +81,34 @@ def child(cases, seed):
     print(json.dumps(stats))
 
 
+def facade(cases, seed):
+    """The same mutations through the C++ facade in a process of its own (tests/cpp/fullprover_harness.cpp): it must exit
+    by itself -- state / error codes of fullprover.hpp -- never by a signal."""
+    import zkey_builder as zb
+    rs = np.random.RandomState(seed)
+    d = tempfile.mkdtemp()
+    toy_z = open(os.path.join(ROOT, "tests", "golden", "toy", "toy_1.zkey"), "rb").read()
+    toy_w = open(os.path.join(ROOT, "tests", "golden", "toy", "toy.wtns"), "rb").read()
+    exe = os.path.join(ROOT, "keyless-zk-proofs_amd", "fullprover_harness")
+    outcomes, signals, t0 = {}, [], time.time()
+    for c in range(cases):
+        which = rs.randint(3)
+        open(d + "/m.zkey", "wb").write(mutate(rs, toy_z, "z") if which != 1 else toy_z)
+        open(d + "/m.wtns", "wb").write(mutate(rs, toy_w, "w") if which != 0 else toy_w)
+        r = subprocess.run([exe, d + "/m.zkey", d + "/m.wtns", "1"], capture_output=True, text=True, timeout=300)
+        if r.returncode < 0:
+            signals.append({"case": c, "signal": -r.returncode})
+        first = [l for l in r.stdout.splitlines() if l.startswith(("state=", "type="))]
+        key = " ".join(l.split(" ms=")[0] for l in first)
+        outcomes[key] = outcomes.get(key, 0) + 1
+    print(json.dumps({"fuzz": "mutated toy .zkey / .wtns through the C++ FullProver facade (one process per case)", "cases": cases,
+                      "seed": seed, "outcomes": outcomes, "killed_by_signal": signals, "seconds": round(time.time() - t0, 1)}))
+    sys.exit(1 if signals else 0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--facade":
+        facade(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         child(int(sys.argv[2]), int(sys.argv[3]))
         sys.exit(0)
