@@ -542,8 +542,10 @@ def main():
         if chunked:
             for k in range(steps):
                 res = exchange(ctx.msm_device(k16.G1, d_bases, d_scalars, n)[0])
-        # (not with torch.distributed: its Python-side calls and the producer then fight over the interpreter lock)
-        elif depth == 1 or os.environ.get("K16_BENCH_THREADED", "1" if dist is None else "0") == "0":
+        # One host path for N = 1 and N > 1 (a 1 -> 8 scaling curve must not mix a host-side change into "scaling"): the
+        # producer thread below, also under torch.distributed -- the exchange is issued by THIS thread only, the producer
+        # calls nothing but the C entry points (ctypes drops the interpreter lock around them).
+        elif depth == 1 or os.environ.get("K16_BENCH_THREADED", "1") == "0":
             for k in range(min(depth - 1, steps)):
                 enqueue()
             for k in range(steps):
@@ -650,7 +652,7 @@ def main():
     if rank == 0:
         _, got_aff = k16.points_sum(k16.G1, np.frombuffer(result, dtype=np.uint8).reshape(1, 128))
         result_checked = bool(got_aff == scalar_times_g(ctx, k16, k_all))
-        if not result_checked:
+        if not result_checked and not os.environ.get("K16_BENCH_NOCHECK"):   # (probe runs produce wrong results on purpose)
             raise SystemExit("bench.py: MSM result differs from the closed form sum s_i (i+1) * G")
 
     # ---- the proof leg (every rank proves; rank 0 reports)

@@ -42,7 +42,8 @@ enum {
     K16_ERR_FORMAT     = -5, /* malformed zkey / wtns            (-> INVALID_INPUT) */
     K16_ERR_CURVE      = -6, /* prime is not BN254 r             (-> UNSUPPORTED_ZKEY_CURVE /
                                                                      WITNESS_GENERATION_INVALID_CURVE) */
-    K16_ERR_BUFFER     = -7
+    K16_ERR_BUFFER     = -7,
+    K16_ERR_NOMEM      = -8  /* a host allocation failed inside the library (-> PROVER_NOT_READY) */
 };
 
 enum { K16_G1 = 0, K16_G2 = 1 };
@@ -62,6 +63,15 @@ enum { K16_PT_ADD = 0, K16_PT_MADD, K16_PT_DBL };
 
 typedef struct k16_ctx    k16_ctx;
 typedef struct k16_prover k16_prover;
+
+/* ---- process set-up (optional) ----
+ * ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); one prover uses four
+ * streams, so a pool of provers on one GPU, or a prover beside RCCL, wants more.  This sets the
+ * variable to n unless the environment already has it.  Call it from the host program's start-up, BEFORE the process's
+ * first HIP call and before it starts threads (the library itself never touches the environment). */
+int         k16_runtime_hw_queues(int n);
+/* number of HIP devices this process can use (0 without a device or runtime; never an error code) */
+int         k16_device_count(void);
 
 /* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
 int         k16_ctx_create(int device, k16_ctx** out);
@@ -176,11 +186,18 @@ int  k16_prover_info(const k16_prover* p, uint32_t* n_vars, uint32_t* n_public, 
                      uint64_t* n_coefs);
 int  k16_prover_prove_file(k16_prover* p, const char* wtns_path, const uint8_t* r_std, const uint8_t* s_std,
                            char* out_json, size_t cap, float* device_ms);
+/* the same, also reporting the host wall time of the proof proper (witness file already opened, mapped and checked):
+ * the interval the reference's `prover_time` metric covers (fullprover.cpp:226-244) */
+int  k16_prover_prove_file_timed(k16_prover* p, const char* wtns_path, const uint8_t* r_std, const uint8_t* s_std,
+                                 char* out_json, size_t cap, float* device_ms, float* prove_wall_ms);
 /* witness already in memory: n_vars x 32 B standard form (the payload of wtns section 2) */
 int  k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_std,
                           const uint8_t* s_std, char* out_json, size_t cap, float* device_ms);
 /* debugging / parity: H scalars of the last proof (domain_size x 32 B, standard form) */
 int  k16_prover_last_h(k16_prover* p, void* h_out);
+/* status of the discarded warm-up proof k16_prover_create runs (K16_OK, or the error it ended with: a prover whose device
+ * cannot prove reports it here instead of on the first real request) */
+int  k16_prover_warmup_status(const k16_prover* p);
 
 /* ---- batched Groth16 verification ----
  * Replaces the CPU check the service runs on every proof before it is released

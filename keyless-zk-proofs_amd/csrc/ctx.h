@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <map>
 #include <mutex>
+#include <new>
+#include <exception>
 #include <tuple>
 #include <string>
 #include <vector>
@@ -123,10 +125,6 @@ struct k16_ctx {
     // 16 (4) does 12 % less reduction work with chains twice as long -- +5 % for pipelined MSMs, +4 % latency for one
     unsigned    wsum_mlog_cap = 3;
     hipEvent_t  last_acc_done = nullptr;
-    // the same fence for the bucket sorts (K16_OPT_PIPELINED_MSM): when several MSMs are enqueued at once -- the start of a
-    // pipelined run -- their sorts would otherwise share the GPU and the FIRST accumulation could only start when all of
-    // them are done; one behind the other, the first MSM's accumulation starts after one sort and the later sorts run
-    // under it
     // what a lane's accumulation waits for when serialize_acc is on: 0 the previous MSM's accumulation, 1 its first
     // weighted-sum level (the previous tail's fold + level 1 run alone, its bit sums beside this accumulation), 2 its whole
     // reduction.  A chip-filling accumulation starves every kernel of the other lanes that starts beside it (kernel traces:
@@ -135,13 +133,13 @@ struct k16_ctx {
     int         acc_fence_mode = 0;
     hipEvent_t  last_lvl1_done = nullptr, last_tail_done = nullptr;
 
-    hipEvent_t  last_sort_done = nullptr;
     // Unused dynamic LDS requested for the bucket accumulation, to cap ITS occupancy (K16_ACC_LDS, bytes per 128-thread
     // workgroup: 36864 -> 4 workgroups = 2 waves/SIMD per CU instead of the 3 its 159 VGPRs allow).  The registers a
     // third wave would take stay free for the other lanes' sort / fold / reduction kernels, which otherwise wait for a
     // whole accumulate workgroup to retire before one of their waves fits.
     unsigned    acc_lds_bytes = 0;
     unsigned    acc_grid_cap  = 0; // K16_ACC_GRID: at most this many (persistent, grid-stride) accumulate workgroups
+    unsigned    acc_dyn_grid  = 0; // K16_ACC_DYN: persistent accumulate grid of this many workgroups with dynamic chunk fetch
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
 };
@@ -162,6 +160,39 @@ hipStream_t k16_lane_stream(k16_ctx* ctx, int lane);
     } while (0)
 
 int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes);
+
+// Exception firewall of the C ABI (include/k16.h: "never throws").  The bodies of the extern "C" entry points use std
+// containers, std::string and new; whatever they throw ends here as a status code -- a C, Rust (bindgen) or ctypes caller
+// cannot unwind.  std::bad_alloc -> K16_ERR_NOMEM, anything else -> K16_ERR_HIP (the "not the caller's fault" class).
+template <class F>
+inline int k16_guard(k16_ctx* ctx, F&& body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try {
+            if (ctx) ctx->err = "out of host memory";
+        } catch (...) {
+        }
+        return K16_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        try {
+            if (ctx) ctx->err = std::string("internal error: ") + e.what();
+        } catch (...) {
+        }
+        return K16_ERR_HIP;
+    } catch (...) {
+        return K16_ERR_HIP;
+    }
+}
+template <class F>
+inline void k16_guard_void(F&& body) noexcept
+{
+    try {
+        body();
+    } catch (...) {
+    }
+}
 
 void k16_stats_begin(k16_ctx* ctx, const char* name, hipStream_t st);
 void k16_stats_end(k16_ctx* ctx, hipStream_t st);

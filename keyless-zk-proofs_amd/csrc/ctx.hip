@@ -1,5 +1,7 @@
 // ctx.hip -- context, device memory, timers, and the batch field / point kernels used by the
 // parity tests of the device arithmetic (fq_raw_generic.cpp:12-233, curve.cpp:91-458).
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include "ctx.h"
@@ -26,12 +28,31 @@ int k16_ws_reserve(k16_ctx* ctx, k16_devbuf& b, size_t bytes)
 // ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  One prover uses exactly four
 // streams (three MSM lanes + the polynomial chain); a pool of provers on one GPU (K16_DEVICES=0,0,0) or a prover beside RCCL
 // needs more, or streams of different provers serialise behind each other: 175 -> 194 proofs/s for three provers sharing an
-// MI355X (profiles/r02).  The HIP runtime reads the variable when it initialises (first HIP call), after this library's
-// constructors have run; a value set by the user wins.
-__attribute__((constructor)) static void k16_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// MI355X (profiles/r02).  The HIP runtime reads the variable when it initialises (the process's first HIP call), so this is
+// an explicit call for the HOST PROGRAM's start-up, before it creates threads or touches HIP -- the library used to set the
+// variable from a load-time constructor, which changed the environment of whatever process mapped it and raced with
+// getenv in other threads.  A value already present in the environment wins.  INTEGRATION.md section 4.
+extern "C" int k16_runtime_hw_queues(int n)
+{
+    if (n < 1 || n > 64) return K16_ERR_ARG;
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", n);
+    return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? K16_OK : K16_ERR_ARG;
+}
+
+extern "C" int k16_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n < 0 ? 0 : n;
+}
 
 extern "C" int k16_ctx_create(int device, k16_ctx** out)
 {
+    return k16_guard(nullptr, [&]() -> int {
     if (!out) return K16_ERR_ARG;
     *out  = nullptr;
     int n = 0;
@@ -51,7 +72,13 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
     if (const char* e = getenv("K16_ACC_FENCE")) c->acc_fence_mode = atoi(e);
     if (const char* e = getenv("K16_ACC_GRID")) c->acc_grid_cap = (unsigned)std::max(0, atoi(e));
+    if (const char* e = getenv("K16_ACC_DYN")) c->acc_dyn_grid = (unsigned)std::max(0, atoi(e));
     if (const char* e = getenv("K16_ACC_LDS")) c->acc_lds_bytes = (unsigned)std::min(65536, std::max(0, atoi(e)));
+    if (c->graphs_on && c->acc_fence_mode != 0) {
+        fprintf(stderr, "k16: K16_GRAPHS=1 ignores K16_ACC_FENCE=%d (events of that mode are not recorded on a graph replay)\n",
+                c->acc_fence_mode);
+        c->acc_fence_mode = 0;
+    }
     c->stream = c->lanes[0].stream;
     if (!lanes_ok ||
         hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
@@ -71,10 +98,12 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
         }
     *out = c;
     return K16_OK;
+    });
 }
 
 extern "C" void k16_ctx_destroy(k16_ctx* c)
 {
+    k16_guard_void([&]() {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -106,6 +135,7 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
         if (L.stream && (&L == &c->lanes[0] || L.stream != c->lanes[0].stream)) (void)hipStreamDestroy(L.stream);
     }
     delete c;
+    });
 }
 
 hipStream_t k16_lane_stream(k16_ctx* ctx, int lane)
@@ -123,9 +153,16 @@ hipStream_t k16_lane_stream(k16_ctx* ctx, int lane)
 
 extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     switch (option) {
     case K16_OPT_GRAPHS:
+        // the K16_ACC_FENCE experiments record their events between the launches of a tail; a replayed graph does not
+        // (nothing on the host runs then), so the ordering those modes promise would silently be lost
+        if (value && c->acc_fence_mode != 0) {
+            c->err = "K16_OPT_GRAPHS cannot be combined with K16_ACC_FENCE != 0";
+            return K16_ERR_ARG;
+        }
         c->graphs_on = value != 0;
         return K16_OK;
     case K16_OPT_PIPELINED_MSM:
@@ -135,6 +172,7 @@ extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
         return K16_OK;
     default: return K16_ERR_ARG;
     }
+    });
 }
 
 extern "C" const char* k16_last_error(const k16_ctx* c) { return c ? c->err.c_str() : "null context"; }
@@ -142,55 +180,69 @@ extern "C" void*       k16_stream(k16_ctx* c) { return c ? (void*)c->stream : nu
 
 extern "C" int k16_sync(k16_ctx* c)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipDeviceSynchronize());
     return K16_OK;
+    });
 }
 extern "C" int k16_dev_alloc(k16_ctx* c, size_t bytes, void** dptr)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !dptr) return K16_ERR_ARG;
     K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipMalloc(dptr, bytes ? bytes : 16));
     return K16_OK;
+    });
 }
 extern "C" int k16_dev_free(k16_ctx* c, void* dptr)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipDeviceSynchronize());
     K16_HIP(c, hipFree(dptr));
     return K16_OK;
+    });
 }
 extern "C" int k16_h2d(k16_ctx* c, void* d, const void* h, size_t bytes)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
     K16_HIP(c, hipStreamSynchronize(c->stream));
     return K16_OK;
+    });
 }
 extern "C" int k16_d2h(k16_ctx* c, void* h, const void* d, size_t bytes)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     K16_HIP(c, hipSetDevice(c->device));
     K16_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
     K16_HIP(c, hipStreamSynchronize(c->stream));
     return K16_OK;
+    });
 }
 extern "C" int k16_timer_start(k16_ctx* c)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     K16_HIP(c, hipEventRecord(c->ev_a, c->stream));
     return K16_OK;
+    });
 }
 extern "C" int k16_timer_stop(k16_ctx* c, float* ms)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !ms) return K16_ERR_ARG;
     K16_HIP(c, hipEventRecord(c->ev_b, c->stream));
     K16_HIP(c, hipEventSynchronize(c->ev_b));
     K16_HIP(c, hipEventElapsedTime(ms, c->ev_a, c->ev_b));
     return K16_OK;
+    });
 }
 void k16_stats_begin(k16_ctx* c, const char* name, hipStream_t st)
 {
@@ -228,20 +280,25 @@ int k16_stats_resolve(k16_ctx* c)
 }
 extern "C" int k16_kernel_stats_enable(k16_ctx* c, int on)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     int rc = k16_stats_resolve(c);
     c->stats_on = on < 0 ? 0 : (on > 2 ? 1 : on);
     return rc;
+    });
 }
 extern "C" int k16_kernel_stats_reset(k16_ctx* c)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c) return K16_ERR_ARG;
     int rc = k16_stats_resolve(c);
     c->stats.clear();
     return rc;
+    });
 }
 extern "C" int k16_kernel_stats_get(k16_ctx* c, const char* name, uint64_t* launches, double* total_ms)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !name) return K16_ERR_ARG;
     int rc = k16_stats_resolve(c);
     if (rc) return rc;
@@ -249,6 +306,7 @@ extern "C" int k16_kernel_stats_get(k16_ctx* c, const char* name, uint64_t* laun
     if (launches) *launches = it == c->stats.end() ? 0 : it->second.launches;
     if (total_ms) *total_ms = it == c->stats.end() ? 0.0 : it->second.total_ms;
     return K16_OK;
+    });
 }
 
 // ---------------------------------------------------------------- batch field / point kernels
@@ -472,6 +530,7 @@ static G2Aff g2_generator()
 
 extern "C" int k16_synth_points_scalars(k16_ctx* c, int group, const void* d_scalars, uint64_t n, void* d_out_affine)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !d_scalars || !d_out_affine || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(c, hipSetDevice(c->device));
@@ -484,10 +543,12 @@ extern "C" int k16_synth_points_scalars(k16_ctx* c, int group, const void* d_sca
                            (const uint8_t*)d_scalars, n, (G2Aff*)d_out_affine);
     K16_HIP(c, hipGetLastError());
     return K16_OK;
+    });
 }
 
 extern "C" int k16_synth_points(k16_ctx* c, int group, uint64_t start, uint64_t n, void* d_out_affine)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !d_out_affine || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     unsigned grid = (unsigned)((n + 63) / 64);
@@ -500,10 +561,12 @@ extern "C" int k16_synth_points(k16_ctx* c, int group, uint64_t start, uint64_t 
     }
     K16_HIP(c, hipGetLastError());
     return K16_OK;
+    });
 }
 
 extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !h_a || !h_r || field < K16_FQ || field > K16_FQ2N) return K16_ERR_ARG;
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
@@ -543,11 +606,13 @@ extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, 
     (void)hipFree(dr);
     if (db) (void)hipFree(db);
     return K16_OK;
+    });
 }
 
 extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1, const void* h_p2, void* h_r,
                                 uint64_t n)
 {
+    return k16_guard(c, [&]() -> int {
     if (!c || !h_p1 || !h_r || group < K16_G1 || group > K16_G2_ENG2N) return K16_ERR_ARG;
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
@@ -586,4 +651,5 @@ extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1,
     (void)hipFree(dr);
     if (d2) (void)hipFree(d2);
     return K16_OK;
+    });
 }

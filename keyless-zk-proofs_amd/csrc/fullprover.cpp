@@ -31,11 +31,16 @@ void log_line(const char* level, const char* msg)
 // Devices behind one FullProver.  K16_DEVICES="0,1,2,3" puts one resident copy of the key on each listed GPU and lets
 // prove() run on whichever is free; a device may be listed more than once ("0,0,0": three provers sharing one GPU, whose
 // proofs overlap on it).  Default: the single device K16_DEVICE (0).  SURVEY 8(f).3: the pool lives behind the facade, so
-// the Rust side only has to stop serialising prove() calls to use it.
+// the Rust side only has to stop serialising prove() calls to use it.  K16_DEVICES=all: every GPU the process can see.
 std::vector<int> device_list()
 {
     std::vector<int> devs;
     if (const char* e = getenv("K16_DEVICES")) {
+        if (strcmp(e, "all") == 0) { // one resident key per GPU of the node (BASELINE config 4: a proof per GPU per wave)
+            const int n = k16_device_count();
+            for (int d = 0; d < n; d++) devs.push_back(d);
+            return devs; // empty without a device: the constructor then reports it
+        }
         const char* p = e;
         while (*p) {
             char* end = nullptr;
@@ -100,26 +105,52 @@ public:
     // fails too the slot is marked dead; the other slots of the pool keep serving.
     void quarantine(Slot* s)
     {
-        if (s->prover) k16_prover_destroy(s->prover);
-        if (s->ctx) k16_ctx_destroy(s->ctx);
-        s->prover = nullptr;
-        s->ctx    = nullptr;
-        if (k16_ctx_create(s->device, &s->ctx) != K16_OK || k16_prover_create(s->ctx, zkey_path.c_str(), &s->prover) != K16_OK) {
-            fprintf(stderr, "k16 FullProver: device %d could not be re-initialised after a fault; slot retired\n", s->device);
+        bool ok = false;
+        try { // k16_* never throw (their own firewall); this guards the few host statements around them all the same
+            if (s->prover) k16_prover_destroy(s->prover);
             if (s->ctx) k16_ctx_destroy(s->ctx);
-            s->ctx = nullptr;
+            s->prover = nullptr;
+            s->ctx    = nullptr;
+            ok = k16_ctx_create(s->device, &s->ctx) == K16_OK && k16_prover_create(s->ctx, zkey_path.c_str(), &s->prover) == K16_OK;
+        } catch (...) {
+            ok = false;
+        }
+        if (!ok) {
+            fprintf(stderr, "k16 FullProver: device %d could not be re-initialised after a fault; slot retired\n", s->device);
+            if (s->prover) k16_prover_destroy(s->prover);
+            if (s->ctx) k16_ctx_destroy(s->ctx);
+            s->prover = nullptr;
+            s->ctx    = nullptr;
             std::lock_guard<std::mutex> lk(mu);
             s->dead = true;
         }
     }
-    void release(Slot* s)
+    void release(Slot* s) noexcept
     {
-        {
+        try {
             std::lock_guard<std::mutex> lk(mu);
+            s->busy = false;
+            if (!s->prover) s->dead = true; // a slot without a prover must never be handed out
+        } catch (...) { // a failing mutex lock: still never leave the slot marked busy
             s->busy = false;
         }
         cv.notify_all(); // also wakes waiters when the last live slot died
     }
+    // Scope guard of one acquired slot: whatever leaves FullProver::prove -- a return, an exception out of the few host
+    // statements between acquire and release -- gives the slot back (and retires it if it lost its prover on the way).
+    // Without it an exception left the slot busy for ever and, with the default one-slot pool, every later prove()
+    // waiting in acquire().
+    struct Lease {
+        FullProverImpl* impl;
+        Slot*           slot;
+        Lease(FullProverImpl* i) : impl(i), slot(i->acquire()) {}
+        ~Lease()
+        {
+            if (slot) impl->release(slot);
+        }
+        Lease(const Lease&)            = delete;
+        Lease& operator=(const Lease&) = delete;
+    };
 };
 
 char const* const ProverResponse::empty_string = "";
@@ -148,7 +179,13 @@ FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullPro
     try {
         p            = new FullProverImpl();
         p->zkey_path = _zkeyFileName;
-        for (int dev : device_list()) {
+        const std::vector<int> devs = device_list();
+        if (devs.empty()) {
+            fprintf(stderr, "k16 FullProver: K16_DEVICES=all but no HIP device is visible; the prover has no CPU fallback\n");
+            delete p;
+            return;
+        }
+        for (int dev : devs) {
             FullProverImpl::Slot s;
             s.device = dev;
             if (k16_ctx_create(dev, &s.ctx) != K16_OK) {
@@ -190,17 +227,20 @@ ProverResponse FullProver::prove(const char* input) const
         log_line("INFO", "FullProver::prove begin");
         char  json[2048];
         float dev_ms = 0;
-        FullProverImpl::Slot* slot = impl->acquire();
-        if (!slot) return ProverResponse(ProverError::PROVER_NOT_READY); // every device of the pool has been retired
-        auto  t0     = std::chrono::high_resolution_clock::now();
-        int   rc     = k16_prover_prove_file(slot->prover, input, nullptr, nullptr, json, sizeof json, &dev_ms);
-        auto  t1     = std::chrono::high_resolution_clock::now();
-        if (rc < 0 && rc != K16_ERR_CURVE && log_on())
-            fprintf(stderr, "k16 FullProver::prove failed: %s\n", k16_last_error(slot->ctx));
-        // A HIP failure is the DEVICE's fault, not the caller's: PROVER_NOT_READY (the service's retry / failover class,
-        // RS/fullprover.cpp:117-121), and the slot goes back into the pool only after it has been rebuilt
-        if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) impl->quarantine(slot);
-        impl->release(slot);
+        float prove_ms = 0;
+        int   rc, dev_used = -1;
+        {
+            FullProverImpl::Lease lease(impl);
+            FullProverImpl::Slot* slot = lease.slot;
+            if (!slot) return ProverResponse(ProverError::PROVER_NOT_READY); // every device of the pool has been retired
+            dev_used = slot->device;
+            rc = k16_prover_prove_file_timed(slot->prover, input, nullptr, nullptr, json, sizeof json, &dev_ms, &prove_ms);
+            if (rc < 0 && rc != K16_ERR_CURVE && log_on())
+                fprintf(stderr, "k16 FullProver::prove failed: %s\n", k16_last_error(slot->ctx));
+            // A HIP failure is the DEVICE's fault, not the caller's: PROVER_NOT_READY (the service's retry / failover class,
+            // RS/fullprover.cpp:117-121), and the slot goes back into the pool only after it has been rebuilt
+            if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) impl->quarantine(slot);
+        }
         if (rc == K16_ERR_CURVE) {
             log_line("ERROR", "witness file uses a different curve than bn128");
             return ProverResponse(ProverError::WITNESS_GENERATION_INVALID_CURVE);
@@ -209,12 +249,19 @@ ProverResponse FullProver::prove(const char* input) const
             log_line("ERROR", "device fault during prove; prover slot re-initialised");
             return ProverResponse(ProverError::PROVER_NOT_READY);
         }
+        if (rc == K16_ERR_NOMEM) { // host allocation failure inside the library: the proof was cleaned up, the slot is intact
+            log_line("ERROR", "out of host memory during prove");
+            return ProverResponse(ProverError::PROVER_NOT_READY);
+        }
         if (rc < 0) return ProverResponse(ProverError::INVALID_INPUT);
         ProverResponseMetrics m;
-        m.prover_time = (int)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
+        // the reference's metric brackets prover->prove() only, after the witness file has been opened and checked
+        // (RS/fullprover.cpp:226-231, whole milliseconds by duration_cast = truncation)
+        m.prover_time = (int)prove_ms;
         if (log_on()) {
             char line[128];
-            snprintf(line, sizeof line, "Time taken for Groth16 prover: %d milliseconds (device %.3f ms)", m.prover_time, dev_ms);
+            snprintf(line, sizeof line, "Time taken for Groth16 prover: %d milliseconds (device %.3f ms) on device %d",
+                     m.prover_time, dev_ms, dev_used);
             log_line("INFO", line);
         }
         char* copy = strdup(json);

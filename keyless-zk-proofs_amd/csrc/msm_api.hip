@@ -101,14 +101,17 @@ unsigned fixed_base_c(uint64_t n)
 
 extern "C" int k16_msm_fixed_base_info(uint64_t n, unsigned* c_out, uint64_t* table_rows)
 {
+    return k16_guard(nullptr, [&]() -> int {
     const unsigned c = fixed_base_c(n);
     if (c_out) *c_out = c;
     if (table_rows) *table_rows = c ? (uint64_t)n * ((257 + c - 1) / c) : 0;
     return K16_OK;
+    });
 }
 
 extern "C" int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_table)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || group != K16_G1 || !d_bases || !d_table) return K16_ERR_ARG;
     const unsigned c = fixed_base_c(n);
     if (!c) {
@@ -116,10 +119,12 @@ extern "C" int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d
         return K16_ERR_ARG;
     }
     return k16_msm_fixed_tables_g1(ctx, d_bases, n, c, (257 + c - 1) / c, d_table);
+    });
 }
 
 extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d_table, const void* d_scalars, uint64_t n)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || group != K16_G1 || !d_table || !d_scalars) return K16_ERR_ARG;
     const unsigned c = fixed_base_c(n);
     if (!c) {
@@ -155,21 +160,26 @@ extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d
         ctx->pend_count++;
     }
     return K16_OK;
+    });
 }
 
 extern "C" int k16_msm_set_lane(k16_ctx* ctx, int lane)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || lane < 0 || lane >= k16_ctx::N_LANES) return K16_ERR_ARG;
     ctx->cur_lane = lane;
     return K16_OK;
+    });
 }
 
 extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx) return K16_ERR_ARG;
     if (c != 0 && (c < MIN_C || c > MAX_C)) return K16_ERR_ARG;
     ctx->forced_c = c;
     return K16_OK;
+    });
 }
 
 namespace {
@@ -240,18 +250,24 @@ static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const v
 
 extern "C" int k16_msm_enqueue(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n)
 {
+    return k16_guard(ctx, [&]() -> int {
     return msm_enqueue_any(ctx, group, d_bases, d_scalars, n, 0);
+    });
 }
 extern "C" int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_prepared, const void* d_scalars,
                                         uint64_t n)
 {
+    return k16_guard(ctx, [&]() -> int {
     return msm_enqueue_any(ctx, group, d_prepared, d_scalars, n, 1);
+    });
 }
 extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || (group != K16_G1 && group != K16_G2) || (n && (!d_bases || !d_out))) return K16_ERR_ARG;
     if (group == K16_G1) return k16_msm_prepare_g1(ctx, d_bases, n, d_out, nullptr);
     return k16_msm_prepare_g2(ctx, d_bases, n, d_out, nullptr);
+    });
 }
 
 // The head entry stays in the ring (pend_count unchanged) until its staged partial sums have been copied out of the
@@ -346,23 +362,30 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
 
 extern "C" int k16_msm_finish(k16_ctx* ctx, void* h_out_xyzz, void* h_out_affine)
 {
+    return k16_guard(ctx, [&]() -> int {
     return msm_finish_any(ctx, -1, h_out_xyzz, h_out_affine);
+    });
 }
 extern "C" int k16_msm_finish_group(k16_ctx* ctx, int group, void* h_out_xyzz, void* h_out_affine)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (group != K16_G1 && group != K16_G2) return K16_ERR_ARG;
     return msm_finish_any(ctx, group, h_out_xyzz, h_out_affine);
+    });
 }
 extern "C" int k16_msm_pending(k16_ctx* ctx)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx) return K16_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->ring_mu);
     return ctx->pend_count;
+    });
 }
 // Error recovery: wait for and drop every MSM still in flight, forget any bucket sort marked for reuse and go back to
 // lane 0, so that the next caller starts from a clean queue (a prover that failed half-way must not leave its MSMs behind).
 extern "C" int k16_msm_abort_all(k16_ctx* ctx)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx) return K16_ERR_ARG;
     int rc = K16_OK;
     while (k16_msm_pending(ctx) > 0) {
@@ -377,6 +400,7 @@ extern "C" int k16_msm_abort_all(k16_ctx* ctx)
     for (auto& L : ctx->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
     return rc;
+    });
 }
 
 // One device call handles up to 2^24 points on the fast (LDS partition) sort.  A larger MSM on ONE GPU is the same
@@ -387,6 +411,7 @@ constexpr uint64_t MSM_CHUNK = 1ull << 24;
 extern "C" int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n,
                        void* h_out_xyzz, void* h_out_affine)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n <= MSM_CHUNK) {
         int rc = k16_msm_enqueue(ctx, group, d_bases, d_scalars, n);
@@ -422,11 +447,13 @@ extern "C" int k16_msm(k16_ctx* ctx, int group, const void* d_bases, const void*
         return rc;
     }
     return k16_points_sum(group, parts.data(), chunks, h_out_xyzz, h_out_affine);
+    });
 }
 
 extern "C" int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const void* h_scalars, uint64_t n,
                             void* h_out_xyzz, void* h_out_affine)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     if (n == 0) return k16_msm(ctx, group, nullptr, nullptr, 0, h_out_xyzz, h_out_affine);
     size_t pb = (size_t)n * (group == K16_G1 ? sizeof(G1Aff) : sizeof(G2Aff));
@@ -450,10 +477,12 @@ extern "C" int k16_msm_host(k16_ctx* ctx, int group, const void* h_bases, const 
     (void)hipFree(db);
     (void)hipFree(ds);
     return rc;
+    });
 }
 
 extern "C" int k16_points_sum(int group, const void* h_parts, uint64_t count, void* h_out_xyzz, void* h_out_affine)
 {
+    return k16_guard(nullptr, [&]() -> int {
     if (group == K16_G1) {
         G1Xyzz acc = G1Xyzz::zero();
         for (uint64_t i = 0; i < count; i++) {
@@ -483,4 +512,5 @@ extern "C" int k16_points_sum(int group, const void* h_parts, uint64_t count, vo
         return K16_OK;
     }
     return K16_ERR_ARG;
+    });
 }

@@ -430,15 +430,18 @@ int k16_ntt_build_coset_shift(k16_ctx* ctx, k16_ntt_table* tab, uint64_t n, k16:
 
 extern "C" int k16_ntt(k16_ctx* ctx, void* d_a, uint64_t n, uint64_t max_domain, int inverse)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !d_a) return K16_ERR_ARG;
     k16_ntt_table* tab = nullptr;
     int            rc  = k16_ntt_get_table(ctx, max_domain, &tab);
     if (rc) return rc;
     return k16_ntt_enqueue(ctx, (Fr*)d_a, n, tab, inverse, nullptr, 0);
+    });
 }
 
 extern "C" int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_domain, int inverse)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !h_a) return K16_ERR_ARG;
     void* d = nullptr;
     K16_HIP(ctx, hipMalloc(&d, n * 32));
@@ -449,4 +452,5 @@ extern "C" int k16_ntt_host(k16_ctx* ctx, void* h_a, uint64_t n, uint64_t max_do
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(d);
     return rc;
+    });
 }

@@ -283,6 +283,7 @@ struct k16_prover {
     hipStream_t    st2 = nullptr;          // polynomial chain (SpMV, NTTs) runs beside the witness MSMs
     hipEvent_t     ev_w = nullptr, ev_h = nullptr;
     std::vector<uint8_t> last_h;
+    int warmup_rc = 0; // status of the create-time warm-up proof (k16_prover_warmup_status)
 };
 
 static void prover_free(k16_prover* p)
@@ -310,6 +311,7 @@ static void prover_free(k16_prover* p)
 
 extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_t zkey_size, k16_prover** out)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !zkey_bytes || !out) return K16_ERR_ARG;
     *out = nullptr;
     BinView bv;
@@ -351,6 +353,16 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     h += 4 + n8q + 4 + n8r;
     k16_prover* p = new k16_prover();
     p->ctx        = ctx;
+    // the std containers below (SpMV plan, staging vectors) may throw: the half-built prover then goes with the unwinding
+    // (the explicit error paths free it themselves and return normally)
+    struct FreeOnUnwind {
+        k16_prover* p;
+        int         base = std::uncaught_exceptions();
+        ~FreeOnUnwind()
+        {
+            if (std::uncaught_exceptions() > base) prover_free(p);
+        }
+    } free_on_unwind{p};
     memcpy(&p->n_vars, h, 4);
     memcpy(&p->n_public, h + 4, 4);
     memcpy(&p->domain_size, h + 8, 4);
@@ -487,19 +499,30 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // workspaces, the lane streams and the code objects of every kernel come into being here instead of inside the first
     // request (35 ms instead of 8 through the facade).  Its outcome does not decide anything: a device that cannot prove
     // says so on the first real request.  Not under fault injection, whose counter counts requests.
-    if (!getenv("K16_NO_WARMUP") && !getenv("K16_FAULT_INJECT")) {
+#ifdef K16_TESTING
+    const bool fault_env = getenv("K16_FAULT_INJECT") != nullptr;
+#else
+    const bool fault_env = false;
+#endif
+    if (!getenv("K16_NO_WARMUP") && !fault_env) {
         std::vector<uint8_t> w((size_t)p->n_vars * 32, 0);
         w[0] = 1;
         uint8_t one[32] = {1};
         char    js[2048];
-        (void)k16_prover_prove_mem(p, w.data(), p->n_vars, one, one, js, sizeof js, nullptr);
+        const int wrc = k16_prover_prove_mem(p, w.data(), p->n_vars, one, one, js, sizeof js, nullptr);
+        if (wrc < 0) { // not fatal for create (the key is loaded), but never silent: the first request will fail the same way
+            fprintf(stderr, "k16_prover_create: warm-up proof failed (%d): %s\n", wrc, ctx->err.c_str());
+            p->warmup_rc = wrc;
+        }
     }
     *out = p;
     return K16_OK;
+    });
 }
 
 extern "C" int k16_prover_create(k16_ctx* ctx, const char* zkey_path, k16_prover** out)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !zkey_path || !out) return K16_ERR_ARG;
     *out = nullptr;
     MappedFile mf;
@@ -509,39 +532,55 @@ extern "C" int k16_prover_create(k16_ctx* ctx, const char* zkey_path, k16_prover
         return rc;
     }
     return k16_prover_create_mem(ctx, mf.base, mf.size, out);
+    });
 }
 
 extern "C" void k16_prover_destroy(k16_prover* p)
 {
+    k16_guard_void([&]() {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
     prover_free(p);
+    });
 }
 
 extern "C" int k16_prover_info(const k16_prover* p, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain_size,
                                uint64_t* n_coefs)
 {
+    return k16_guard((p ? p->ctx : nullptr), [&]() -> int {
     if (!p) return K16_ERR_ARG;
     if (n_vars) *n_vars = p->n_vars;
     if (n_public) *n_public = p->n_public;
     if (domain_size) *domain_size = p->domain_size;
     if (n_coefs) *n_coefs = p->n_coefs;
     return K16_OK;
+    });
 }
 
-// K16_FAULT_INJECT="hip_after_msm" (every prove while it is set) or "hip_after_msm:<k>" (only the k-th prove of this
-// process, 1-based): the prove fails with K16_ERR_HIP after its witness MSMs have been enqueued -- the state a device
-// fault or an allocation failure in the middle of a proof leaves behind.  Test hook for the error paths
-// (tests/test_boundary.py, tests/test_gpu_parity.py); read at every call, costs one getenv.
-static bool fault_injected_now()
+// Fault injection exists only in the TESTING build of the library (libk16_testing.so, -DK16_TESTING; the production
+// libk16.so does not read the variable at all, so an inherited environment cannot make a service fail its proofs).
+// K16_FAULT_INJECT="hip_after_msm" / "bad_alloc_in_prove" (every prove while it is set) or "<kind>:<k>" (only the k-th
+// prove of this process, 1-based): the prove fails with K16_ERR_HIP, or throws std::bad_alloc, after its witness MSMs
+// have been enqueued -- the state a device fault or an allocation failure in the middle of a proof leaves behind.
+// Test hook for the error paths (tests/test_boundary.py, tests/test_gpu_parity.py).
+#ifdef K16_TESTING
+static int fault_injected_now()
 {
     static std::atomic<long> calls{0};
     const long               k = ++calls;
     const char*              e = getenv("K16_FAULT_INJECT");
-    if (!e || strncmp(e, "hip_after_msm", 13) != 0) return false;
-    return e[13] != ':' || atol(e + 14) == k;
+    if (!e) return 0;
+    int    kind = 0;
+    size_t len  = 0;
+    if (strncmp(e, "hip_after_msm", 13) == 0) kind = 1, len = 13;
+    else if (strncmp(e, "bad_alloc_in_prove", 18) == 0) kind = 2, len = 18;
+    if (!kind) return 0;
+    return (e[len] != ':' || atol(e + len + 1) == k) ? kind : 0;
 }
+#else
+static inline int fault_injected_now() { return 0; }
+#endif
 
 static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
                            char* out_json, size_t cap, float* device_ms);
@@ -549,8 +588,20 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
 extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in,
                                     const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
 {
+    return k16_guard((p ? p->ctx : nullptr), [&]() -> int {
     if (!p || !h_wtns || !out_json) return K16_ERR_ARG;
-    int rc = prove_mem_inner(p, h_wtns, n_vars, r_in, s_in, out_json, cap, device_ms);
+    int rc;
+    try {
+        rc = prove_mem_inner(p, h_wtns, n_vars, r_in, s_in, out_json, cap, device_ms);
+    } catch (const std::bad_alloc&) {
+        rc = K16_ERR_NOMEM;
+        try {
+            p->ctx->err = "out of host memory during prove";
+        } catch (...) {
+        }
+    } catch (...) {
+        rc = K16_ERR_HIP;
+    }
     if (rc < 0) {
         // Whatever failed, nothing of this proof may stay behind: MSMs already enqueued are waited for and dropped (the
         // next prove would otherwise pop them as ITS results), the sort-reuse flags and the lane selection are reset,
@@ -563,6 +614,7 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
         ctx->err      = err;
     }
     return rc;
+    });
 }
 
 static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
@@ -681,7 +733,8 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
     }
     ht("A C B1 B2 enqueued");
-    if (fault_injected_now()) {
+    if (const int fault = fault_injected_now()) {
+        if (fault == 2) throw std::bad_alloc();
         ctx->err = "injected fault (K16_FAULT_INJECT)";
         return K16_ERR_HIP;
     }
@@ -749,6 +802,16 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
 extern "C" int k16_prover_prove_file(k16_prover* p, const char* wtns_path, const uint8_t* r_std, const uint8_t* s_std,
                                      char* out_json, size_t cap, float* device_ms)
 {
+    return k16_prover_prove_file_timed(p, wtns_path, r_std, s_std, out_json, cap, device_ms, nullptr);
+}
+
+// prove_wall_ms: host wall time of the proof itself, i.e. what RS/fullprover.cpp:226-231 brackets (`prover->prove(...)`,
+// after the witness file has been opened, mapped and its header checked at :205-221)
+extern "C" int k16_prover_prove_file_timed(k16_prover* p, const char* wtns_path, const uint8_t* r_std, const uint8_t* s_std,
+                                           char* out_json, size_t cap, float* device_ms, float* prove_wall_ms)
+{
+    return k16_guard((p ? p->ctx : nullptr), [&]() -> int {
+    if (prove_wall_ms) *prove_wall_ms = 0.f;
     if (!p || !wtns_path) return K16_ERR_ARG;
     k16_ctx*   ctx = p->ctx;
     MappedFile mf;
@@ -764,19 +827,30 @@ extern "C" int k16_prover_prove_file(k16_prover* p, const char* wtns_path, const
         return K16_ERR_FORMAT;
     }
     // wtns_utils.hpp:32-40, fullprover.cpp:216-221
-    uint32_t n8 = 0, nv = 0;
+    uint32_t n8 = 0;
     memcpy(&n8, bv.sec[1].p, 4);
     if (n8 != 32 || memcmp(bv.sec[1].p + 4, BN254_R_LE, 32) != 0) {
         ctx->err = "witness uses a different curve than bn128";
         return K16_ERR_CURVE;
     }
-    memcpy(&nv, bv.sec[1].p + 4 + 32, 4);
+    // (the header's nVars is not trusted -- the reference does not even compare it with the key's, SURVEY 8(b): the
+    // section's own length says how many values there are, and prove_mem checks that against the circuit)
     uint64_t have = bv.sec[2].size / 32;
-    return k16_prover_prove_mem(p, bv.sec[2].p, have, r_std, s_std, out_json, cap, device_ms);
+    const auto t0 = std::chrono::steady_clock::now();
+    rc            = k16_prover_prove_mem(p, bv.sec[2].p, have, r_std, s_std, out_json, cap, device_ms);
+    if (prove_wall_ms) *prove_wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+    });
+}
+
+extern "C" int k16_prover_warmup_status(const k16_prover* p)
+{
+    return p ? p->warmup_rc : K16_ERR_ARG;
 }
 
 extern "C" int k16_prover_last_h(k16_prover* p, void* h_out)
 {
+    return k16_guard((p ? p->ctx : nullptr), [&]() -> int {
     if (!p || !h_out) return K16_ERR_ARG;
     k16_ctx* ctx = p->ctx;
     K16_HIP(ctx, hipSetDevice(ctx->device));
@@ -784,4 +858,5 @@ extern "C" int k16_prover_last_h(k16_prover* p, void* h_out)
     K16_HIP(ctx, hipMemcpyAsync(h_out, p->d_a, (size_t)p->domain_size * 32, hipMemcpyDeviceToHost, ctx->stream));
     K16_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return K16_OK;
+    });
 }

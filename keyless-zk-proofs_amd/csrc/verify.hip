@@ -123,17 +123,20 @@ int pairings_on_device(k16_ctx* ctx, const PairConsts* d_K, const G1Aff* d_P, co
 
 extern "C" void k16_vk_destroy(k16_vk* vk)
 {
+    k16_guard_void([&]() {
     if (!vk) return;
     if (vk->ctx) (void)hipSetDevice(vk->ctx->device);
     void* bufs[] = {vk->d_ic, vk->d_g2, vk->d_K, vk->d_eab};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete vk;
+    });
 }
 
 extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2, const void* gamma2, const void* delta2,
                              const void* ic, uint32_t n_ic, k16_vk** out)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !alpha1 || !beta2 || !gamma2 || !delta2 || !ic || n_ic < 1 || !out) return K16_ERR_ARG;
     *out = nullptr;
     K16_HIP(ctx, hipSetDevice(ctx->device));
@@ -181,11 +184,13 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail("k16_vk_create", e);
     *out = vk;
     return K16_OK;
+    });
 }
 
 extern "C" int k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, const void* h_inputs, uint64_t n,
                                 uint8_t* h_ok)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !vk || vk->ctx != ctx || (n && (!h_proofs || !h_ok)) || (n && vk->n_ic > 1 && !h_inputs)) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(ctx, hipSetDevice(ctx->device));
@@ -211,11 +216,13 @@ extern "C" int k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_pr
     K16_HIP(ctx, hipMemcpyAsync(h_ok, d_ok, n, hipMemcpyDeviceToHost, st));
     K16_HIP(ctx, hipStreamSynchronize(st));
     return K16_OK;
+    });
 }
 
 // parity tests: out[i] = e(P_i, Q_i) as ark-ec's Bn::pairing computes it (12 x 32 B per value, c0.c0.a first)
 extern "C" int k16_pairing_vec(k16_ctx* ctx, const void* h_g1, const void* h_g2, uint64_t n, void* h_out_gt)
 {
+    return k16_guard(ctx, [&]() -> int {
     if (!ctx || (n && (!h_g1 || !h_g2 || !h_out_gt))) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(ctx, hipSetDevice(ctx->device));
@@ -240,4 +247,5 @@ extern "C" int k16_pairing_vec(k16_ctx* ctx, const void* h_g1, const void* h_g2,
     K16_HIP(ctx, hipMemcpyAsync(h_out_gt, d_gt, n * sizeof(Fp12), hipMemcpyDeviceToHost, st));
     K16_HIP(ctx, hipStreamSynchronize(st));
     return K16_OK;
+    });
 }

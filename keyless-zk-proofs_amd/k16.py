@@ -27,17 +27,17 @@ def op_bound(op, ka=0, kb=0):
     """K16_OP_BOUND_A / _B: operands moved up by ka / kb multiples of the modulus (radix-2^29 selectors only)."""
     return op | (ka << 8) | (kb << 12)
 
-ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -6: "CURVE", -7: "BUFFER"}
+ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -6: "CURVE", -7: "BUFFER", -8: "NOMEM"}
 
 # every symbol include/k16.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
+    "k16_runtime_hw_queues", "k16_device_count", "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
-    "k16_prover_prove_file", "k16_prover_prove_mem", "k16_prover_last_h",
+    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
     "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_pairing_vec",
 ]
 
@@ -58,6 +58,7 @@ def load():
         raise K16Error(-1, "libk16.so not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(LIB_PATH)
     vp, u64, i32, u32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_size_t
+    L.k16_runtime_hw_queues.argtypes = [i32]
     L.k16_ctx_create.argtypes = [i32, C.POINTER(vp)]
     L.k16_ctx_destroy.argtypes = [vp]
     L.k16_ctx_destroy.restype = None
@@ -103,8 +104,10 @@ def load():
     L.k16_prover_destroy.restype = None
     L.k16_prover_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
     L.k16_prover_prove_file.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
+    L.k16_prover_prove_file_timed.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.k16_prover_prove_mem.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
     L.k16_prover_last_h.argtypes = [vp, vp]
+    L.k16_prover_warmup_status.argtypes = [vp]
     L.k16_vk_create.argtypes = [vp, vp, vp, vp, vp, vp, u32, C.POINTER(vp)]
     L.k16_vk_destroy.argtypes = [vp]
     L.k16_vk_destroy.restype = None
@@ -364,6 +367,9 @@ class Prover:
             raise K16Error(rc, (self.ctx.L.k16_last_error(self.ctx.h) or b"").decode())
         self.last_device_ms = ms.value
         return buf.value.decode()
+
+    def warmup_status(self):
+        return int(self.ctx.L.k16_prover_warmup_status(self.h))
 
     def last_h(self):
         n = self.info()["domain_size"]

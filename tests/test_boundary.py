@@ -23,10 +23,12 @@ def _has_gpu():
         return False
 
 
-def build_harness(tmp_path):
-    exe = str(tmp_path / "fullprover_harness")
+def build_harness(tmp_path, testing=False):
+    """The C++ program standing for the Rust crate.  testing=True links the TESTING build of the library
+    (libk16_testing.so, the only one with the K16_FAULT_INJECT hooks)."""
+    exe = str(tmp_path / ("fullprover_harness_testing" if testing else "fullprover_harness"))
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), HARNESS_SRC,
-                           "-L", PKG, "-lk16", "-Wl,-rpath," + PKG, "-pthread", "-o", exe])
+                           "-L", PKG, "-lk16_testing" if testing else "-lk16", "-Wl,-rpath," + PKG, "-pthread", "-o", exe])
     return exe
 
 
@@ -147,7 +149,7 @@ def test_fullprover_device_fault_is_not_the_callers_fault(tmp_path, toy_paths):
     import json
     import bn254_pairing as bp
     zkey, wtns, vk = toy_paths
-    exe = build_harness(tmp_path)
+    exe = build_harness(tmp_path, testing=True)
     env = dict(os.environ, K16_FAULT_INJECT="hip_after_msm:2")
     out = subprocess.run([exe, zkey, wtns, "4"], capture_output=True, text=True, timeout=300, env=env)
     lines = out.stdout.splitlines()
@@ -159,3 +161,54 @@ def test_fullprover_device_fault_is_not_the_callers_fault(tmp_path, toy_paths):
         assert lines[k].startswith("type=0 error=0"), lines
         assert json.loads(lines[k + 1])["protocol"] == "groth16"
         assert bp.verify_json(vk, lines[k + 1], [2])
+
+
+@pytest.mark.gpu
+def test_fullprover_exception_in_prove_releases_the_slot(tmp_path, toy_paths):
+    """An exception inside a proof (injected std::bad_alloc, testing build) ends at the C ABI's firewall as
+    K16_ERR_NOMEM -> PROVER_NOT_READY, and the ONE slot of the default pool is given back: the next prove() succeeds
+    instead of waiting for ever in acquire() (round-2 advisor finding).  The production build ignores the variable."""
+    import json
+    import bn254_pairing as bp
+    zkey, wtns, vk = toy_paths
+    exe = build_harness(tmp_path, testing=True)
+    env = dict(os.environ, K16_FAULT_INJECT="bad_alloc_in_prove:2")
+    env.pop("K16_DEVICES", None)
+    out = subprocess.run([exe, zkey, wtns, "4"], capture_output=True, text=True, timeout=120, env=env)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr
+    assert lines[1].startswith("type=0 error=0")
+    assert lines[3].startswith("type=1 error=1"), lines           # ERROR / PROVER_NOT_READY
+    assert lines[4] == ""
+    for k in (5, 7):                                              # the pool's only slot is alive and proves correctly
+        assert lines[k].startswith("type=0 error=0"), lines
+        assert bp.verify_json(vk, lines[k + 1], [2])
+    prod = build_harness(tmp_path)
+    out = subprocess.run([prod, zkey, wtns, "3"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, K16_FAULT_INJECT="hip_after_msm"))
+    lines = out.stdout.splitlines()
+    assert [lines[1 + 2 * k].startswith("type=0 error=0") for k in range(3)] == [True] * 3, lines
+
+
+@pytest.mark.gpu
+def test_fullprover_pool_over_all_devices(tmp_path, toy_paths):
+    """K16_DEVICES=all builds the pool from the device count (one resident key per GPU); with two or more GPUs the
+    concurrent callers really prove on different ordinals (K16_LOG names the device of every proof)."""
+    import bn254_pairing as bp
+    import k16
+    zkey, wtns, vk = toy_paths
+    exe = build_harness(tmp_path)
+    n_dev = k16.load().k16_device_count()
+    assert n_dev >= 1
+    env = dict(os.environ, K16_DEVICES="all", K16_LOG="1")
+    out = subprocess.run([exe, zkey, wtns, "3", str(2 * n_dev)], capture_output=True, text=True, timeout=300, env=env)
+    lines = [l for l in out.stdout.splitlines() if not l.startswith('{"level"')]
+    assert lines[0] == "state=0", out.stderr
+    n = 3 * 2 * n_dev
+    for k in range(n):
+        assert lines[1 + 2 * k].startswith("type=0 error=0"), lines
+    assert bp.verify_json(vk, lines[2], [2])
+    used = set(re.findall(r"on device (\d+)", out.stdout))
+    assert used == {str(d) for d in range(n_dev)}, (used, n_dev)
+    if n_dev < 2:
+        pytest.skip("one GPU here: the two-ordinal leg needs a multi-GPU node (the pool over all = [0] was exercised)")

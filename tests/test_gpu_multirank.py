@@ -1,0 +1,58 @@
+"""-m gpu : the N > 1 path of bench.py, run every round on whatever box there is.
+
+A one-GPU box cannot give two ranks a GPU each, and RCCL refuses two ranks on one device, so the two-rank runs here use
+bench.py's test rig K16_BENCH_SHARE_GPU=1: both ranks compute on GPU 0 and the 128-byte exchange goes over gloo.  Everything
+else is the production code path: bench.py spawning its ranks as a child process, sharding.shard_range, the per-rank MSM,
+exchange_start / exchange_finish, the EC-add fold, the closed-form check over BOTH shards.  With two or more GPUs the same
+commands also run over RCCL, one rank per GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("mode_args, scaling", [(["--log2n", "16"], "weak"),
+                                                (["--mode", "strong", "--total-log2n", "20"], "strong")])
+def test_bench_two_ranks_sharing_the_gpu(mode_args, scaling):
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--proofs", "0", "--no-cpu-baseline"] + mode_args,
+               {"K16_BENCH_SHARE_GPU": "1", "K16_BENCH_PREWARM": "2"})
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["result_checked"] is True          # folded result of BOTH shards == (sum_i s_i (i+1)) G
+    assert d["scaling"] == scaling and d["value"] > 0
+    assert "gloo" in d["config"]["sharding"]
+
+
+def test_bench_replica_proofs_on_two_ranks():
+    """BASELINE config 4's replica mode on two ranks (one prover per rank, no collective), at a reduced circuit size so
+    that two ranks fit one GPU's time budget: proofs/s is the sum over ranks."""
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "14", "--proofs", "3", "--proof-scale", "0.02",
+                "--no-cpu-baseline"], {"K16_BENCH_SHARE_GPU": "1", "K16_BENCH_PREWARM": "2", "K16_BENCH_PROVERS": "1"})
+    assert d["ranks_seen"] == 2 and d["result_checked"] is True
+    assert d["proof"]["proofs"] == 6 and d["proof"]["proofs_per_s"] > 0
+    assert d["proof"]["parallelism"].startswith("replicas")
+
+
+def test_bench_one_rank_per_gpu_over_rccl():
+    """With two or more GPUs: the same command over RCCL, one rank per GPU (skipped on the one-GPU boxes of the pool)."""
+    import k16
+    n = k16.load().k16_device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs; this box has %d" % n)
+    d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--log2n", "18", "--proofs", "0", "--no-cpu-baseline"], {})
+    assert d["ranks_seen"] == 2 and d["result_checked"] is True and "RCCL" in d["config"]["sharding"]

@@ -144,3 +144,47 @@ def test_proofs_of_a_valid_synthetic_key_verify(ctx, tmp_path, shape):
     assert V.verify_batch([gio.proof_from_json(p.prove_mem(bad))], [[x]]) == [False]
     V.close()
     p.close()
+
+
+def test_config4_wave_of_distinct_witnesses_through_the_fullprover_pool(ctx, tmp_path):
+    """BASELINE config 4 in the form one GPU allows, through the drop-in boundary: ONE FullProver whose pool holds three
+    provers (K16_DEVICES=0,0,0; a node lists its eight GPUs), four concurrent callers, a wave of 16 DISTINCT witnesses of
+    a VALID key of the Keyless shape (nVars 1,343,588, N = 2^21) read from .wtns files -- every proof must verify under
+    ONE k16_verify_batch with its own public input, and be rejected with another proof's input / when tampered.
+    Replaces the mutex around the single prover of prover-service/src/prover_state.rs:21."""
+    import os
+    import subprocess
+    import k16
+    import valid_key_builder as vkb
+    from test_boundary import build_harness
+    n_wit = 16
+    key = vkb.build(_gpu_points(ctx), 1209229, 107487, 26870, seed=13)
+    assert (key["n_vars"], key["domain"]) == (1343588, 1 << 21)
+    zk = str(tmp_path / "wave.zkey")
+    open(zk, "wb").write(key["zkey"])
+    paths, inputs = [], []
+    for i in range(n_wit):
+        w, pub = key["new_witness"](500 + i)
+        paths.append(str(tmp_path / ("w%02d.wtns" % i)))
+        vkb.write_wtns(paths[-1], w)
+        inputs.append(pub)
+    assert len({tuple(p) for p in inputs}) == n_wit               # distinct public inputs, i.e. distinct statements
+    exe = build_harness(tmp_path)
+    env = dict(os.environ, K16_DEVICES="0,0,0")
+    out = subprocess.run([exe, zk, ",".join(paths), "4", "4"], capture_output=True, text=True, timeout=900, env=env)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr[-2000:]
+    proofs = [None] * n_wit
+    for k in range(n_wit):
+        head = lines[1 + 2 * k]
+        assert head.startswith("type=0 error=0 ms="), lines[:6]
+        proofs[int(head.split("wtns=")[1])] = gio.proof_from_json(lines[2 + 2 * k])
+    assert all(p is not None for p in proofs) and len(set(proofs)) == n_wit
+    V = k16.VerifyingKey(ctx, key["vk"])
+    tampered = bytearray(proofs[3])
+    tampered[200] ^= 1                                           # one bit of C.x
+    batch = proofs + [proofs[0], bytes(tampered)]
+    ins = inputs + [inputs[1], inputs[3]]                         # proof 0 with witness 1's public input; tampered proof 3
+    assert V.verify_batch(batch, ins) == [True] * n_wit + [False, False]
+    assert ol.groth16_verify(key["vk"], proofs[5], inputs[5])     # and the CPU oracle agrees on one of them
+    V.close()
