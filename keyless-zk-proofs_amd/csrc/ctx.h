@@ -139,6 +139,9 @@ struct k16_ctx {
     // whole accumulate workgroup to retire before one of their waves fits.
     unsigned    acc_lds_bytes = 0;
     unsigned    acc_grid_cap  = 0; // K16_ACC_GRID: at most this many (persistent, grid-stride) accumulate workgroups
+    // every kernel of the bucket sort in <= 32 VGPRs, so that it is resident BESIDE another lane's bucket accumulation
+    // (msm_kernels.inc, "lean sort"); set with K16_OPT_PIPELINED_MSM, or K16_LEAN_SORT=0/1
+    bool        lean_sort     = false;
     unsigned    acc_dyn_grid  = 0; // K16_ACC_DYN: persistent accumulate grid of this many workgroups with dynamic chunk fetch
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;

@@ -72,6 +72,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
     if (const char* e = getenv("K16_ACC_FENCE")) c->acc_fence_mode = atoi(e);
     if (const char* e = getenv("K16_ACC_GRID")) c->acc_grid_cap = (unsigned)std::max(0, atoi(e));
+    if (const char* e = getenv("K16_LEAN_SORT")) c->lean_sort = atoi(e) != 0;
     if (const char* e = getenv("K16_ACC_DYN")) c->acc_dyn_grid = (unsigned)std::max(0, atoi(e));
     if (const char* e = getenv("K16_ACC_LDS")) c->acc_lds_bytes = (unsigned)std::min(65536, std::max(0, atoi(e)));
     if (c->graphs_on && c->acc_fence_mode != 0) {
@@ -169,6 +170,9 @@ extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
         // several MSMs in flight on different lanes, throughput over latency
         c->serialize_acc = value != 0;
         c->wsum_mlog_cap = value ? 4 : 3;
+        // (the lean sort -- every sort kernel in <= 32 VGPRs, resident beside another lane's accumulation -- is NOT switched
+        // on here: measured, it moves the sort under the accumulation but the step does not get shorter, the chip being
+        // power-limited during a pipelined run (profiles/r03/lean_sort_and_power.md); K16_LEAN_SORT=1 selects it)
         return K16_OK;
     default: return K16_ERR_ARG;
     }

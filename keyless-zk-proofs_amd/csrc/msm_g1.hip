@@ -25,7 +25,13 @@ int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
         // captured graphs -- a graph would pin this call's table pointer); otherwise it is a kernel of its own
         const bool fuse = n <= (1u << 24) && !ctx->reuse_sort && !ctx->graphs_on && getenv("K16_ATOMIC_SORT") == nullptr &&
                           getenv("K16_NO_FUSED_CONVERT") == nullptr;
-        if (fuse)
+        if (ctx->lean_sort) {
+            // lean sort: the counting pass stays at 25 VGPRs (the fused conversion made it 82), and the conversion is the
+            // 5-doubling kernel -- both fit beside another lane's bucket accumulation
+            hipLaunchKernelGGL(k_convert_bases_lean, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0,
+                               k16_lane_stream(ctx, ctx->cur_lane), (const uint4*)d_bases, (uint4*)L.ws_conv.p, 2 * n);
+            K16_HIP(ctx, hipGetLastError());
+        } else if (fuse)
             conv_in = d_bases;
         else if ((rc = k16_msm_prepare_g1(ctx, d_bases, n, L.ws_conv.p, k16_lane_stream(ctx, ctx->cur_lane))))
             return rc;
