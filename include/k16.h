@@ -220,6 +220,11 @@ int  k16_vk_create(k16_ctx* ctx, const void* alpha1_g1, const void* beta2_g2, co
 void k16_vk_destroy(k16_vk* vk);
 int  k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, const void* h_inputs, uint64_t n,
                       uint8_t* h_out_ok);
+/* Small batches (n <= K16_VERIFY_COOP_MAX, default 2048) of k16_verify_batch run ONE WAVEFRONT PER PROOF (a static program
+ * of ~2000 steps of <= 64 independent field operations, csrc/verify_script.h): 1-2 ms for one proof or for a wave of 64,
+ * where one lane per pairing needs ~45 ms -- the latency the per-proof check of prover_handler.rs:329-336 needs.  Same
+ * flags.  parity tests: the GT value that path computes for every proof, e(A,B) e(vk_x,-gamma) e(C,-delta), 12 x 32 B per proof */
+int  k16_verify_coop_gt(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, const void* h_inputs, uint64_t n, void* h_out_gt);
 /* parity tests: out[i] = e(P_i, Q_i) exactly as ark-ec's Bn::pairing gives it, 12 x 32 B per value (Fq12 = Fq6[w]/(w^2 - v),
  * Fq6 = Fq2[v]/(v^3 - 9 - u): c0.c0.a, c0.c0.b, c0.c1.a, ...), Montgomery form */
 int  k16_pairing_vec(k16_ctx* ctx, const void* h_g1, const void* h_g2, uint64_t n, void* h_out_gt);

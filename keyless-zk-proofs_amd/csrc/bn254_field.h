@@ -266,6 +266,95 @@ K16_HD Fp<PR> finv(const Fp<PR>& a)
     return fpow(a, e);
 }
 
+// The same value as finv (Montgomery form of a^-1; inv(0) = 0) by the binary extended Euclidean algorithm instead of
+// Fermat's 254 squarings + ~127 multiplications: ~500 shift / subtract steps on eight limbs, i.e. ~20 multiplication times
+// instead of ~380 for ONE element.  For latency-critical single inversions (the wave-cooperative verifier); the batched
+// kernels keep finv, whose lanes stay in lockstep.  x = aR, plain inverse y = x^-1 mod p, result a^-1 R = y * R^3 / R.
+template <class PR>
+__host__ __device__ __attribute__((noinline)) Fp<PR> finv_bgcd(const Fp<PR>& a)
+{
+    if (a.is_zero()) return a;
+    uint32_t u[8], v[8], x1[8], x2[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u[i]  = a.v[i];
+        v[i]  = PR::P[i];
+        x1[i] = i == 0 ? 1u : 0u;
+        x2[i] = 0u;
+    }
+    auto is_one = [](const uint32_t* w) {
+        uint32_t o = w[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < 8; i++) o |= w[i];
+        return o == 0;
+    };
+    auto shr1 = [](uint32_t* w, uint32_t top) { // (top:w) >> 1
+#pragma unroll
+        for (int i = 0; i < 7; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+        w[7] = (w[7] >> 1) | (top << 31);
+    };
+    auto half_mod = [&](uint32_t* x) { // x / 2 mod p, x < p
+        uint32_t carry = 0;
+        if (x[0] & 1u) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint64_t t = (uint64_t)x[i] + PR::P[i] + carry;
+                x[i]       = (uint32_t)t;
+                carry      = (uint32_t)(t >> 32);
+            }
+        }
+        shr1(x, carry);
+    };
+    auto geq = [](const uint32_t* p, const uint32_t* q) {
+        for (int i = 7; i >= 0; i--)
+            if (p[i] != q[i]) return p[i] > q[i];
+        return true;
+    };
+    auto sub = [](uint32_t* p, const uint32_t* q) -> uint32_t { // p -= q, returns the borrow
+        uint32_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)p[i] - q[i] - br;
+            p[i]       = (uint32_t)t;
+            br         = (uint32_t)(t >> 63);
+        }
+        return br;
+    };
+    auto sub_mod = [&](uint32_t* p, const uint32_t* q) { // p = p - q mod P
+        if (sub(p, q)) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                uint64_t t = (uint64_t)p[i] + PR::P[i] + carry;
+                p[i]       = (uint32_t)t;
+                carry      = (uint32_t)(t >> 32);
+            }
+        }
+    };
+#pragma clang loop unroll(disable)
+    for (int guard = 0; guard < 1100 && !is_one(u) && !is_one(v); guard++) {
+        if (!(u[0] & 1u)) {
+            shr1(u, 0);
+            half_mod(x1);
+        } else if (!(v[0] & 1u)) {
+            shr1(v, 0);
+            half_mod(x2);
+        } else if (geq(u, v)) {
+            (void)sub(u, v);
+            sub_mod(x1, x2);
+        } else {
+            (void)sub(v, u);
+            sub_mod(x2, x1);
+        }
+    }
+    Fp<PR> y;
+    const uint32_t* src = is_one(u) ? x1 : x2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) y.v[i] = src[i];
+    const Fp<PR> r2 = Fp<PR>::r2();
+    return fmul(y, fmul(r2, r2)); // y * R^3 / R
+}
+
 typedef Fp<FqParams> Fq;
 typedef Fp<FrParams> Fr;
 

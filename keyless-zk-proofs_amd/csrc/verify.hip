@@ -10,8 +10,11 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
 #include "ctx.h"
 #include "bn254_pairing.h"
+#include "bn254_fq9.h"
+#include "verify_script.h"
 
 using namespace k16;
 
@@ -22,6 +25,14 @@ struct k16_vk {
     G2Aff*      d_g2  = nullptr; // [0] -gamma, [1] -delta  (ark-groth16 PreparedVerifyingKey::gamma_g2_neg_pc / delta_g2_neg_pc)
     PairConsts* d_K   = nullptr;
     Fp12*       d_eab = nullptr; // e(alpha, beta)           (PreparedVerifyingKey::alpha_g1_beta_g2)
+    // the wave-cooperative path (one wavefront per proof; verify_script.h): the program, this key's constant table
+    // (curve constants, e(alpha, beta), line coefficients of -gamma and -delta) and 4-bit window tables of IC[1..]
+    bool        coop      = false;
+    uint64_t*   d_words   = nullptr;
+    uint32_t *  d_terms = nullptr, *d_hdr = nullptr, *d_chunks = nullptr, *d_ctab9 = nullptr;
+    G1Aff*      d_wtab    = nullptr; // [(n_ic - 1) * 64 windows][16 digits]: digit * 16^window * IC[j + 1]
+    Fq*         d_target  = nullptr; // e(alpha, beta), 12 canonical values
+    uint32_t    n_chunks = 0, chunk_words = 0, lds_bytes = 0;
 };
 
 namespace {
@@ -93,6 +104,302 @@ __global__ void __launch_bounds__(64) k_pair_final(const Fp12* __restrict__ f, u
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The wave-cooperative verifier: ONE wavefront checks one proof by interpreting the static program of verify_script.h.
+// Slot file in LDS: field elements in the unsaturated radix-2^29 representation of bn254_fq9.h (9 limbs, values < 2p,
+// R' = 2^261): a multiplication is fmul9, a linear combination is 64-bit limb-wise accumulation (no carries between
+// terms) followed by ONE partial reduction.  Exact mod p throughout; the result is made canonical at the end.
+struct CoopDev {
+    const uint64_t* words;
+    const uint32_t *terms, *hdr, *chunks;
+    uint32_t        n_chunks, chunk_words, n_const, in_base, n_slots, target_const;
+    uint32_t        out_slot[12];
+};
+constexpr uint32_t COOP_CHUNK_BYTES = 32768;
+
+__device__ __forceinline__ Fq9 coop_ld9(const uint32_t* slots, uint32_t s)
+{
+    Fq9 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = slots[s * 9 + k];
+    return r;
+}
+__device__ __forceinline__ void coop_st9(uint32_t* slots, uint32_t s, const Fq9& v)
+{
+#pragma unroll
+    for (int k = 0; k < 9; k++) slots[s * 9 + k] = v.l[k];
+}
+template <class T>
+__device__ __forceinline__ T coop_shfl_down(const T& v, unsigned delta)
+{
+    static_assert(sizeof(T) % 4 == 0, "dword granularity");
+    T               r;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(&v);
+    uint32_t*       d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) d[i] = (uint32_t)__shfl_down((int)s[i], delta, 64);
+    return r;
+}
+
+// status[i]: 0 rejected, 1 accepted, 2 "not decided here" (vk_x is the point at infinity: the general path decides)
+__global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* __restrict__ ctab9, const G1Aff* __restrict__ wtab,
+                                                    const G1Aff* __restrict__ ic, uint32_t n_ic,
+                                                    const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ inputs,
+                                                    const Fq* __restrict__ target, uint8_t* __restrict__ status,
+                                                    Fq* __restrict__ gt_out, uint64_t* __restrict__ dbg)
+{
+    // dbg (K16_VERIFY_COOP_TRACE=1, proof 0 only): 100 MHz time stamps -- start, constants copied, vk_x done, inputs stored,
+    // program done -- then the ticks spent staging chunks and in multiply / linear / inversion steps
+    uint64_t tk[4] = {0, 0, 0, 0}, t_last = 0;
+    auto     stamp = [&](int i) {
+        if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    extern __shared__ uint32_t coop_lds[];
+    uint32_t*      slots = coop_lds;
+    uint32_t*      buf   = coop_lds + ((D.n_slots * 9 + 3) & ~3u);
+    const unsigned lane  = threadIdx.x;
+    const uint64_t pi    = blockIdx.x;
+    // ---- constants of the key -> slots [0, n_const)
+    {
+        const uint4* csrc = reinterpret_cast<const uint4*>(ctab9); // (table padded to a multiple of 4 words by the host)
+        uint4*       cdst = reinterpret_cast<uint4*>(slots);
+        for (uint32_t k = lane; k < (D.n_const * 9 + 3) / 4; k += 64) cdst[k] = csrc[k];
+    }
+    // ---- vk_x = IC[0] + sum_j x_j IC[j+1] (ark-groth16 prepare_inputs): one table row per (input, 4-bit window), a lane
+    // per window, then a shuffle tree.  x_j acts as a 256-bit integer (G1 has order r), as in the general path.
+    stamp(1);
+    G1Xyzz acc = G1Xyzz::zero();
+    for (uint32_t idx = lane; idx < (n_ic - 1) * 64; idx += 64) {
+        const uint32_t j = idx >> 6, w = idx & 63;
+        const uint8_t  byte = inputs[(pi * (n_ic - 1) + j) * 32 + (w >> 1)];
+        const uint32_t d    = (w & 1) ? (byte >> 4) : (byte & 15);
+        if (d) acc = padd_mixed(acc, wtab[(size_t)idx * 16 + d]);
+    }
+#pragma clang loop unroll(disable)
+    for (unsigned d = 32; d >= 1; d >>= 1) {
+        G1Xyzz o = coop_shfl_down(acc, d); // (lanes >= 64 - d read their own value: their sums are not used)
+        acc      = padd(acc, o);
+    }
+    uint32_t undecided = 0;
+    Fq       vk_s[3] = {Fq::zero(), Fq::zero(), Fq::zero()}; // X ZZZ, Y ZZ, ZZ ZZZ: vk_x stays projective (verify_script.h)
+    if (lane == 0) {
+        acc = padd_mixed(acc, ic[0]);
+        if (acc.is_zero()) {
+            undecided = 1;
+        } else {
+            vk_s[0] = fmul(acc.x, acc.zzz);
+            vk_s[1] = fmul(acc.y, acc.zz);
+            vk_s[2] = fmul(acc.zz, acc.zzz);
+        }
+    }
+    undecided = (uint32_t)__shfl((int)undecided, 0, 64);
+    if (undecided) { // uniform
+        if (lane == 0) status[pi] = 2;
+        return;
+    }
+    stamp(2);
+    // ---- inputs -> slots: A.x A.y | B.x.a B.x.b B.y.a B.y.b | C.x C.y | vk_x as (X ZZZ, Y ZZ, ZZ ZZZ)
+    {
+        Fq v = Fq::zero();
+        if (lane < 8) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(proofs + pi * 256 + lane * 32);
+#pragma unroll
+            for (int k = 0; k < 8; k++) v.v[k] = src[k];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t x = (uint32_t)__shfl((int)vk_s[j].v[k], 0, 64);
+                if (lane == 8 + j) v.v[k] = x;
+            }
+        const Fq9 v9 = fq9_from_fq(v);
+        if (lane < COOP_N_INPUTS) coop_st9(slots, D.in_base + lane, v9);
+    }
+    __syncthreads();
+    stamp(3);
+    // ---- the program
+    constexpr int64_t MASK = (1 << 29) - 1;
+    // the chunk table itself sits in LDS (behind the staging buffer): a chunk then costs one global round trip, not two
+    uint32_t* ctab = buf + D.chunk_words;
+    for (uint32_t k = lane; k < D.n_chunks * 4; k += 64) ctab[k] = D.chunks[k];
+    __syncthreads();
+#pragma clang loop unroll(disable)
+    for (uint32_t c = 0; c < D.n_chunks; c++) {
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c]),
+                       ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 1]),
+                       tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 2]),
+                       nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 3]);
+        // one wavefront: LDS operations of a wave complete in program order, so a value stored by one lane is seen by the
+        // loads any lane issues later -- no barrier anywhere in this loop, only the compiler is told not to move LDS
+        // accesses across the step boundaries
+        uint32_t* hdrs = buf + ns * 128 + ((nt + 3) & ~3u);
+        if (dbg) t_last = __builtin_amdgcn_s_memrealtime();
+        {
+            const uint4* wsrc = reinterpret_cast<const uint4*>(D.words + (size_t)s0 * 64);
+            uint4*       wdst = reinterpret_cast<uint4*>(buf);
+            for (uint32_t k = lane; k < ns * 32; k += 64) wdst[k] = wsrc[k];
+            for (uint32_t k = lane; k < nt; k += 64) buf[ns * 128 + k] = D.terms[tb + k];
+            for (uint32_t k = lane; k < ns; k += 64) hdrs[k] = D.hdr[s0 + k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (dbg) {
+            const uint64_t now = __builtin_amdgcn_s_memrealtime();
+            tk[0] += now - t_last;
+            t_last = now;
+        }
+        // the header and the instruction word of step s + 1 are loaded while step s executes (a lone wavefront has nobody to
+        // hide an LDS round trip behind, and these two would head every step's dependency chain)
+        uint32_t h_nx = hdrs[0], wlo_nx = buf[lane * 2], whi_nx = buf[lane * 2 + 1];
+#pragma clang loop unroll(disable)
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t h     = (uint32_t)__builtin_amdgcn_readfirstlane((int)h_nx); // class | longest combination << 8
+            const uint32_t cls   = h & 0xff;
+            const uint32_t wlo = wlo_nx, whi = whi_nx;
+            if (s + 1 < ns) {
+                h_nx   = hdrs[s + 1];
+                wlo_nx = buf[((s + 1) * 64 + lane) * 2];
+                whi_nx = buf[((s + 1) * 64 + lane) * 2 + 1];
+            }
+            const bool     valid = whi >> 31;
+            const uint32_t dst   = wlo & 0x3fff;
+            Fq9            r;
+            if (cls == CS_MUL) {
+                const uint32_t a = valid ? (wlo >> 14) & 0x3fff : 0u, b = valid ? ((wlo >> 28) | (whi << 4)) & 0x3fff : 0u;
+                r = fmul9(coop_ld9(slots, a), coop_ld9(slots, b));
+            } else if (cls == CS_LIN) {
+                // A linear combination is evaluated by THREE lanes: lane 3j + g accumulates limbs 3g .. 3g+2 of every term
+                // (a third of the loads and multiply-adds per lane), the quotient by p comes from the top lane, and the
+                // carries travel lane to lane once at the end.
+                const uint32_t maxt = h >> 8;
+                const uint32_t l16  = lane & 15;
+                const uint32_t g    = l16 - 3 * ((l16 * 11) >> 5); // l16 % 3 for l16 < 16 (lane 15 of a row is idle)
+                const uint32_t lb   = 3 * g;
+                const uint32_t ntl  = valid ? (wlo >> 14) & 0x3f : 0u;
+                const uint32_t t0   = ((wlo >> 20) | ((whi & 0xfff) << 12)) - tb;
+                // limb-wise 64-bit accumulation on top of 2^15 p (keeps the total positive: the negative coefficients of a
+                // combination sum to at most COOP_MAX_COEF = 2^12 times values < 4p)
+                const uint32_t p0 = lb == 0 ? Fq9C::P[0] : lb == 3 ? Fq9C::P[3] : Fq9C::P[6];
+                const uint32_t p1 = lb == 0 ? Fq9C::P[1] : lb == 3 ? Fq9C::P[4] : Fq9C::P[7];
+                const uint32_t p2 = lb == 0 ? Fq9C::P[2] : lb == 3 ? Fq9C::P[5] : Fq9C::P[8];
+                int64_t        a3[3] = {(int64_t)p0 << 15, (int64_t)p1 << 15, (int64_t)p2 << 15};
+                // COOP_TRIP terms per trip (the host pads every combination to a multiple of it with 0 x slot 0), all loads of a
+                // trip issued before the first use: a lone wavefront has nobody to hide an LDS round trip behind, and a trip
+                // has two dependent ones (term words, then slot limbs).  No per-term tests.
+                const uint32_t ntp = (ntl + COOP_TRIP - 1) & ~(COOP_TRIP - 1);
+                (void)maxt;
+#pragma clang loop unroll(disable)
+                for (uint32_t t = 0; t < ntp; t += COOP_TRIP) {
+                    uint32_t tw[COOP_TRIP], lim[COOP_TRIP][3];
+#pragma unroll
+                    for (int u = 0; u < (int)COOP_TRIP; u++) tw[u] = buf[ns * 128 + t0 + t + u];
+#pragma unroll
+                    for (int u = 0; u < (int)COOP_TRIP; u++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) lim[u][k] = slots[(tw[u] & 0xffff) * 9 + lb + k];
+#pragma unroll
+                    for (int u = 0; u < (int)COOP_TRIP; u++) {
+                        const int32_t cf = (int32_t)tw[u] >> 16;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) a3[k] += (int64_t)cf * (int64_t)(int32_t)lim[u][k]; // v_mad_i64_i32
+                    }
+                }
+                // the quotient by p, estimated from the two top accumulators (lane g = 2 holds limbs 6, 7, 8; p / 2^232 =
+                // 3171406.3; 2^44 / 3171407 = 5547122.9) and taken low: the result is non-negative and below 5p -- fine
+                // for fmul9, whose operand bounds may multiply to 128
+                const uint64_t top_est = (uint64_t)(a3[2] + (a3[1] >> 29));                       // < 2^38
+                int64_t        q       = (int64_t)(((top_est >> 11) * 5547123ull) >> 33) - 2;      // floor(top / 3171407) - 2 .. - 4
+                q                      = q < 0 ? 0 : q;
+                {   // lane g = 2 of the group has it: row_shl:1 / row_shl:2 bring it to lanes g = 1 / 0  (q < 2^17)
+                    const int q2 = (int)(uint32_t)q;
+                    const int s1 = __builtin_amdgcn_update_dpp(0, q2, 0x101, 0xf, 0xf, true);
+                    const int s2 = __builtin_amdgcn_update_dpp(0, q2, 0x102, 0xf, 0xf, true);
+                    q            = (int64_t)(uint32_t)(g == 2 ? q2 : g == 1 ? s1 : s2);
+                }
+                a3[0] -= q * (int64_t)p0;
+                a3[1] -= q * (int64_t)p1;
+                a3[2] -= q * (int64_t)p2;
+                // carries: lane g = 0 first, then 1 (with 0's carry), then 2; the top limb (limb 8) keeps everything above
+                int64_t  cout = 0;
+                uint32_t o0 = 0, o1 = 0, o2 = 0;
+#pragma unroll
+                for (int round = 0; round < 3; round++) {
+                    const uint32_t clo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)cout, 0x111, 0xf, 0xf, true); // row_shr:1
+                    const uint32_t chi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)cout >> 32), 0x111, 0xf, 0xf, true);
+                    if ((int)g == round) {
+                        const int64_t cin = round == 0 ? 0 : (int64_t)(((uint64_t)chi << 32) | clo);
+                        int64_t       t   = a3[0] + cin;
+                        o0                = (uint32_t)(t & MASK);
+                        t                 = a3[1] + (t >> 29);
+                        o1                = (uint32_t)(t & MASK);
+                        t                 = a3[2] + (t >> 29);
+                        if (round < 2) {
+                            o2   = (uint32_t)(t & MASK);
+                            cout = t >> 29;
+                        } else {
+                            o2 = (uint32_t)t;
+                        }
+                    }
+                }
+                if (valid) {
+                    slots[dst * 9 + lb]     = o0;
+                    slots[dst * 9 + lb + 1] = o1;
+                    slots[dst * 9 + lb + 2] = o2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                if (dbg) {
+                    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+                    tk[cls] += now - t_last;
+                    t_last = now;
+                }
+                continue;
+            } else { // CS_INV
+                r = fq9_zero();
+                if (valid) r = fq9_from_fq(finv_bgcd(fq9_to_fq(coop_ld9(slots, (wlo >> 14) & 0x3fff))));
+            }
+            if (valid) coop_st9(slots, dst, r); // (every lane's operand loads precede this store in program order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (dbg) {
+                const uint64_t now = __builtin_amdgcn_s_memrealtime();
+                tk[cls] += now - t_last;
+                t_last = now;
+            }
+        }
+    }
+    stamp(4);
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0)
+        for (int k = 0; k < 4; k++) dbg[5 + k] = tk[k];
+    // ---- the GT value, canonical, against e(alpha, beta)
+    bool same = true;
+    if (lane < 12) {
+        const Fq v = fq9_to_fq(coop_ld9(slots, D.out_slot[lane]));
+        if (gt_out) gt_out[pi * 12 + lane] = v;
+        same = v == target[lane];
+    }
+    const uint64_t all = __ballot(same);
+    if (lane == 0) status[pi] = all == ~0ull ? 1 : 0;
+}
+
+// the program is the same for every key: built once per process
+const CoopProgram* coop_program()
+{
+    static std::once_flag once;
+    static CoopProgram*   prog = nullptr;
+    std::call_once(once, []() {
+        try {
+            PairConsts K;
+            pairing_consts_init(&K);
+            CoopProgram* p = new CoopProgram();
+            coop_build_program(K, p);
+            prog = p;
+        } catch (...) {
+            prog = nullptr;
+        }
+    });
+    return prog;
+}
+
 struct DevBufs {
     std::vector<void*> p;
     ~DevBufs()
@@ -126,7 +433,8 @@ extern "C" void k16_vk_destroy(k16_vk* vk)
     k16_guard_void([&]() {
     if (!vk) return;
     if (vk->ctx) (void)hipSetDevice(vk->ctx->device);
-    void* bufs[] = {vk->d_ic, vk->d_g2, vk->d_K, vk->d_eab};
+    void* bufs[] = {vk->d_ic, vk->d_g2, vk->d_K, vk->d_eab, vk->d_words, vk->d_terms, vk->d_hdr, vk->d_chunks, vk->d_ctab9,
+                    vk->d_wtab, vk->d_target};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete vk;
@@ -182,8 +490,171 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
         return rc;
     }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail("k16_vk_create", e);
+    // ---- the wave-cooperative path (latency: one wavefront per proof).  Any failure here only leaves it switched off.
+    if (!getenv("K16_VERIFY_NO_COOP")) {
+        const CoopProgram* P = coop_program();
+        Fp12               eab;
+        if (P && hipMemcpy(&eab, vk->d_eab, sizeof eab, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<Ell> l1, l2;
+            coop_prepare_lines(neg[0], K, &l1);
+            coop_prepare_lines(neg[1], K, &l2);
+            std::vector<Fq> ctab;
+            coop_const_table(K, eab, l1, l2, &ctab);
+            std::vector<uint32_t> ctab9((ctab.size() * 9 + 3) & ~(size_t)3, 0u);
+            for (size_t i = 0; i < ctab.size(); i++) {
+                const Fq9 v = fq9_from_fq(ctab[i]);
+                for (int k = 0; k < 9; k++) ctab9[i * 9 + k] = v.l[k];
+            }
+            // window tables: row (j * 64 + w) * 16 + d = d * 16^w * IC[j + 1]   (d = 0 unused)
+            std::vector<G1Aff> wtab((size_t)(n_ic - 1) * 64 * 16);
+            for (uint32_t j = 0; j + 1 < n_ic; j++) {
+                G1Aff base_aff;
+                memcpy(&base_aff, (const uint8_t*)ic + (size_t)(j + 1) * sizeof(G1Aff), sizeof(G1Aff));
+                G1Xyzz base = G1Xyzz::from_aff(base_aff);
+                for (uint32_t w = 0; w < 64; w++) {
+                    G1Xyzz m = base;
+                    for (uint32_t d = 1; d < 16; d++) {
+                        wtab[((size_t)j * 64 + w) * 16 + d] = to_affine(m);
+                        m = padd(m, base);
+                    }
+                    base = m; // 16 * base
+                    wtab[((size_t)j * 64 + w) * 16] = G1Aff{Fq::zero(), Fq::zero()};
+                }
+            }
+            // program -> device: words, terms, per-step header (class | longest combination << 8), chunk table
+            const size_t          n_steps = P->step_class.size();
+            std::vector<uint32_t> hdr(n_steps), chunks;
+            std::vector<uint32_t> step_t0(n_steps, 0), step_nt(n_steps, 0);
+            for (size_t sidx = 0; sidx < n_steps; sidx++) {
+                uint32_t mx = 0, lo = 0xffffffffu, hi = 0;
+                if (P->step_class[sidx] == CS_LIN)
+                    for (int l = 0; l < 64; l++) {
+                        const uint64_t w = P->words[sidx * 64 + l];
+                        if (!(w >> 63)) continue;
+                        const uint32_t nt = (uint32_t)((w >> 14) & 0x3f), t0 = (uint32_t)((w >> 20) & 0xffffff);
+                        mx = std::max(mx, nt);
+                        lo = std::min(lo, t0);
+                        hi = std::max(hi, t0 + ((nt + COOP_TRIP - 1) & ~(COOP_TRIP - 1))); // (combinations are padded to whole trips)
+                    }
+                hdr[sidx]     = P->step_class[sidx] | (mx << 8);
+                step_t0[sidx] = hi ? lo : 0;
+                step_nt[sidx] = hi ? hi - lo : 0;
+            }
+            uint32_t max_chunk_words = 0;
+            for (size_t s0 = 0; s0 < n_steps;) { // greedy: as many consecutive steps as fit the staging buffer
+                size_t   s1 = s0;
+                uint32_t tlo = 0, thi = 0;
+                bool     have = false;
+                while (s1 < n_steps) {
+                    uint32_t nlo = tlo, nhi = thi;
+                    bool     nh  = have;
+                    if (step_nt[s1]) {
+                        nlo = have ? std::min(tlo, step_t0[s1]) : step_t0[s1];
+                        nhi = have ? std::max(thi, step_t0[s1] + step_nt[s1]) : step_t0[s1] + step_nt[s1];
+                        nh  = true;
+                    }
+                    const size_t bytes = (s1 + 1 - s0) * 512 + (size_t)(nh ? nhi - nlo : 0) * 4;
+                    if (bytes > COOP_CHUNK_BYTES && s1 > s0) break;
+                    tlo = nlo, thi = nhi, have = nh;
+                    s1++;
+                }
+                chunks.push_back((uint32_t)s0);
+                chunks.push_back((uint32_t)(s1 - s0));
+                chunks.push_back(have ? tlo : 0);
+                chunks.push_back(have ? thi - tlo : 0);
+                max_chunk_words = std::max<uint32_t>(max_chunk_words, (uint32_t)((s1 - s0) * 129 + (have ? thi - tlo : 0) + 8));
+                s0 = s1;
+            }
+            vk->n_chunks  = (uint32_t)(chunks.size() / 4);
+            vk->chunk_words = (max_chunk_words + 3) & ~3u;
+            vk->lds_bytes   = (((P->n_slots * 9 + 3) & ~3u) + vk->chunk_words + vk->n_chunks * 4) * 4;
+            const Fq2* ev = &eab.c0.c0;
+            Fq         target[12];
+            for (int i = 0; i < 6; i++) {
+                target[2 * i]     = ev[i].a;
+                target[2 * i + 1] = ev[i].b;
+            }
+            auto up = [&](void** d, const void* h, size_t bytes) {
+                return hipMalloc(d, bytes ? bytes : 16) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
+            };
+            vk->coop = vk->lds_bytes <= 160 * 1024 &&
+                       up((void**)&vk->d_words, P->words.data(), P->words.size() * 8) &&
+                       up((void**)&vk->d_terms, P->terms.data(), P->terms.size() * 4) &&
+                       up((void**)&vk->d_hdr, hdr.data(), hdr.size() * 4) && up((void**)&vk->d_chunks, chunks.data(), chunks.size() * 4) &&
+                       up((void**)&vk->d_ctab9, ctab9.data(), ctab9.size() * 4) &&
+                       up((void**)&vk->d_wtab, wtab.data(), wtab.size() * sizeof(G1Aff)) &&
+                       up((void**)&vk->d_target, target, sizeof target) &&
+                       hipFuncSetAttribute((const void*)k_verify_coop, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)vk->lds_bytes) == hipSuccess;
+            if (!vk->coop) (void)hipGetLastError();
+        }
+    }
     *out = vk;
     return K16_OK;
+    });
+}
+
+// returns K16_OK (h_ok filled), 1 (some proof undecided: caller takes the general path), or an error
+static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, const void* h_inputs, uint64_t n, uint8_t* h_ok,
+                       void* h_gt)
+{
+    hipStream_t  st = ctx->stream;
+    DevBufs      tmp;
+    uint8_t *    d_pr = nullptr, *d_in = nullptr, *d_st = nullptr;
+    Fq*          d_gt = nullptr;
+    const size_t in_bytes = (size_t)n * (vk->n_ic - 1) * 32;
+    K16_HIP(ctx, tmp.alloc((void**)&d_pr, (size_t)n * 256));
+    K16_HIP(ctx, tmp.alloc((void**)&d_in, in_bytes));
+    K16_HIP(ctx, tmp.alloc((void**)&d_st, n));
+    if (h_gt) K16_HIP(ctx, tmp.alloc((void**)&d_gt, (size_t)n * 12 * sizeof(Fq)));
+    K16_HIP(ctx, hipMemcpyAsync(d_pr, h_proofs, (size_t)n * 256, hipMemcpyHostToDevice, st));
+    if (in_bytes) K16_HIP(ctx, hipMemcpyAsync(d_in, h_inputs, in_bytes, hipMemcpyHostToDevice, st));
+    const CoopProgram* P = coop_program();
+    CoopDev            D;
+    D.words = vk->d_words;
+    D.terms = vk->d_terms;
+    D.hdr = vk->d_hdr;
+    D.chunks = vk->d_chunks;
+    D.n_chunks = vk->n_chunks;
+    D.chunk_words = vk->chunk_words;
+    D.n_const = P->n_const;
+    D.in_base = P->in_base;
+    D.n_slots = P->n_slots;
+    D.target_const = P->target_const;
+    for (int i = 0; i < 12; i++) D.out_slot[i] = P->out_slot[i];
+    static const bool trace = getenv("K16_VERIFY_COOP_TRACE") != nullptr;
+    uint64_t*         d_dbg = nullptr;
+    if (trace) K16_HIP(ctx, tmp.alloc((void**)&d_dbg, 16 * 8));
+    hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(64), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic, vk->n_ic,
+                       d_pr, d_in, vk->d_target, d_st, d_gt, d_dbg);
+    K16_HIP(ctx, hipGetLastError());
+    if (trace) {
+        uint64_t h[16];
+        K16_HIP(ctx, hipMemcpy(h, d_dbg, sizeof h, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[k16 coop] us: constants %.1f vk_x %.1f inputs %.1f program %.1f | chunk staging %.1f mul %.1f lin %.1f inv %.1f\n",
+                (h[1] - h[0]) / 100.0, (h[2] - h[1]) / 100.0, (h[3] - h[2]) / 100.0, (h[4] - h[3]) / 100.0, h[5] / 100.0, h[6] / 100.0,
+                h[7] / 100.0, h[8] / 100.0);
+    }
+    std::vector<uint8_t> stt(n);
+    K16_HIP(ctx, hipMemcpyAsync(stt.data(), d_st, n, hipMemcpyDeviceToHost, st));
+    if (h_gt) K16_HIP(ctx, hipMemcpyAsync(h_gt, d_gt, (size_t)n * 12 * sizeof(Fq), hipMemcpyDeviceToHost, st));
+    K16_HIP(ctx, hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n; i++)
+        if (stt[i] > 1) return 1;
+    if (h_ok) memcpy(h_ok, stt.data(), n);
+    return K16_OK;
+}
+
+// parity tests: the GT value e(A,B) e(vk_x,-gamma) e(C,-delta) of every proof as the wave-cooperative path computes it
+// (12 x 32 B, Montgomery, c0.c0.a first); K16_ERR_ARG when that path is not available for this key or these inputs
+extern "C" int k16_verify_coop_gt(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, const void* h_inputs, uint64_t n,
+                                  void* h_out_gt)
+{
+    return k16_guard(ctx, [&]() -> int {
+    if (!ctx || !vk || vk->ctx != ctx || !vk->coop || !n || !h_proofs || !h_out_gt || (vk->n_ic > 1 && !h_inputs)) return K16_ERR_ARG;
+    K16_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = verify_coop(ctx, vk, h_proofs, h_inputs, n, nullptr, h_out_gt);
+    return rc == 1 ? K16_ERR_ARG : rc;
     });
 }
 
@@ -195,6 +666,27 @@ extern "C" int k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_pr
     if (n == 0) return K16_OK;
     K16_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // Small batches -- the service's one proof after every prove(), a wave of 64 -- take the wave-cooperative path: one
+    // wavefront per proof, ~1-2 ms whatever n is up to the number of CUs, instead of the ~45 ms one lane needs for a
+    // pairing.  It records the generic case only: a proof with a zero point, or whose vk_x is the point at infinity, sends
+    // the batch to the general path below (same flags: both compute the same GT value for every other proof).
+    static const uint64_t coop_max = getenv("K16_VERIFY_COOP_MAX") ? strtoull(getenv("K16_VERIFY_COOP_MAX"), nullptr, 10) : 2048;
+    if (vk->coop && n <= coop_max) {
+        bool generic = true;
+        for (uint64_t i = 0; i < n && generic; i++) {
+            const uint8_t* pr = (const uint8_t*)h_proofs + i * 256;
+            auto zero = [](const uint8_t* p, size_t len) {
+                for (size_t k = 0; k < len; k++)
+                    if (p[k]) return false;
+                return true;
+            };
+            generic = !zero(pr, 64) && !zero(pr + 64, 128) && !zero(pr + 192, 64);
+        }
+        if (generic) {
+            int rc = verify_coop(ctx, vk, h_proofs, h_inputs, n, h_ok, nullptr);
+            if (rc != 1) return rc; // K16_OK or an error; 1 = a proof was left undecided: general path
+        }
+    }
     DevBufs     tmp;
     uint8_t *   d_pr = nullptr, *d_in = nullptr, *d_ok = nullptr;
     G1Aff*      d_P = nullptr;

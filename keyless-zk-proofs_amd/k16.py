@@ -38,7 +38,7 @@ SYMBOLS = [
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
-    "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_pairing_vec",
+    "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_verify_coop_gt", "k16_pairing_vec",
 ]
 
 _lib = None
@@ -112,6 +112,7 @@ def load():
     L.k16_vk_destroy.argtypes = [vp]
     L.k16_vk_destroy.restype = None
     L.k16_verify_batch.argtypes = [vp, vp, vp, vp, u64, vp]
+    L.k16_verify_coop_gt.argtypes = [vp, vp, vp, vp, u64, vp]
     L.k16_pairing_vec.argtypes = [vp, vp, vp, u64, vp]
     _lib = L
     return L
@@ -409,6 +410,16 @@ class VerifyingKey:
         ok = np.zeros(n, dtype=np.uint8)
         self.ctx._chk(self.ctx.L.k16_verify_batch(self.ctx.h, self.h, _p(pr), _p(inp) if inp.size else None, n, _p(ok)))
         return [bool(v) for v in ok]
+
+    def coop_gt(self, proofs, inputs):
+        """The GT value e(A,B) e(vk_x,-gamma) e(C,-delta) of every proof as the wave-cooperative path computes it
+        (k16_verify_coop_gt): (n, 384) uint8.  Raises K16Error(ARG) when that path does not apply."""
+        n = len(proofs)
+        pr = np.frombuffer(b"".join(bytes(p) for p in proofs), dtype=np.uint8).copy()
+        inp = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for row in inputs for x in row), dtype=np.uint8).copy()
+        out = np.zeros((n, 384), dtype=np.uint8)
+        self.ctx._chk(self.ctx.L.k16_verify_coop_gt(self.ctx.h, self.h, _p(pr), _p(inp) if inp.size else None, n, _p(out)))
+        return out
 
     def close(self):
         if self.h:

@@ -188,3 +188,95 @@ def test_config4_wave_of_distinct_witnesses_through_the_fullprover_pool(ctx, tmp
     assert V.verify_batch(batch, ins) == [True] * n_wit + [False, False]
     assert ol.groth16_verify(key["vk"], proofs[5], inputs[5])     # and the CPU oracle agrees on one of them
     V.close()
+
+
+def _neg_g2(q):
+    """-(x, y) for an affine Montgomery G2 point (Montgomery form is linear: -yR = p - yR)."""
+    q = bytes(q)
+    out = bytearray(q[:64])
+    for k in (64, 96):
+        v = int.from_bytes(q[k:k + 32], "little")
+        out += ((pm.Q - v) % pm.Q).to_bytes(32, "little")
+    return bytes(out)
+
+
+def _check_gt(vk, proof, xs):
+    """e(A,B) e(vk_x,-gamma) e(C,-delta) from the ORACLE's pairing and group operations."""
+    acc = None
+    for j, x in enumerate(xs):
+        t = ol.mul_scalar(0, vk["ic"][j + 1], int(x % (1 << 256)).to_bytes(32, "little"))
+        acc = t if acc is None else ol.pt_op(0, 0, acc, t)
+    vkx = ol.pt_to_affine(0, ol.pt_op(0, 1, acc, vk["ic"][0]))
+    g = ol.pairing(proof[:64], proof[64:192])
+    g = ol.gt_mul(g, ol.pairing(vkx, _neg_g2(vk["gamma2"])))
+    return ol.gt_mul(g, ol.pairing(proof[192:256], _neg_g2(vk["delta2"])))
+
+
+def test_wave_cooperative_verifier_gt_values_and_flags(ctx, toy_paths, monkeypatch):
+    """The latency path of k16_verify_batch (one wavefront per proof, csrc/verify_script.h): the GT value it computes is
+    byte-equal to the oracle's e(A,B) e(vk_x,-gamma) e(C,-delta) for accepted AND rejected proofs, its flags equal the
+    general (one lane per pairing) path's and the oracle's, and inputs it does not cover (a zero point) still get the
+    right flags through the general path.  prover_handler.rs:329-336 is the per-proof check this serves."""
+    import k16
+    zkey, wtns, vkp = toy_paths
+    vk = gio.vk_from_json(vkp)
+    V = k16.VerifyingKey(ctx, vk)
+    known = gio.proof_from_json(KNOWN_RS0)
+    p = k16.Prover(ctx, zkey)
+    fresh = [gio.proof_from_json(p.prove_file(wtns)) for _ in range(3)]
+    p.close()
+    tampered = known[:64] + ol.gen_points(1, 77, 1)[0].tobytes() + known[192:]
+    cases = [(known, 2), (known, 3), (known, 2 + pm.R), (known, 0), (fresh[0], 2), (fresh[1], 2), (fresh[2], 7), (tampered, 2),
+             (known[192:256] + known[64:192] + known[0:64], 2), (known, (1 << 256) - 1)]
+    gts = V.coop_gt([c[0] for c in cases], [[c[1]] for c in cases])
+    for (pr, x), got in zip(cases, gts):
+        assert got.tobytes() == _check_gt(vk, pr, [x]), x
+    eab = ol.pairing(vk["alpha1"], vk["beta2"])
+    want = [ol.groth16_verify(vk, c[0], [c[1]]) for c in cases]
+    assert [g.tobytes() == eab for g in gts] == want
+    assert V.verify_batch([c[0] for c in cases], [[c[1]] for c in cases]) == want          # cooperative path
+    assert want[0] and not want[1] and want[2] and want[4] and want[5] and not want[6] and not want[7]
+    # one proof alone (the service's case), and a batch larger than the number of CUs
+    assert V.verify_batch([known], [[2]]) == [True] and V.verify_batch([known], [[3]]) == [False]
+    big = cases * 60
+    assert V.verify_batch([c[0] for c in big], [[c[1]] for c in big]) == want * 60
+    # a zero point sends the batch to the general path: same flags as before
+    withzero = cases + [(bytes(64) + known[64:], 2)]
+    assert V.verify_batch([c[0] for c in withzero], [[c[1]] for c in withzero]) == want + [ol.groth16_verify(vk, withzero[-1][0], [2])]
+    V.close()
+    # the general path alone (cooperative path switched off at key creation) gives the same flags
+    monkeypatch.setenv("K16_VERIFY_NO_COOP", "1")
+    V2 = k16.VerifyingKey(ctx, vk)
+    assert V2.verify_batch([c[0] for c in cases], [[c[1]] for c in cases]) == want
+    with pytest.raises(k16.K16Error):
+        V2.coop_gt([known], [[2]])
+    V2.close()
+
+
+def test_wave_cooperative_verifier_several_public_inputs(ctx):
+    """n_ic = 4: the window tables of IC[1..3] and the lane-per-window sum of vk_x."""
+    import k16
+    g, h = ol.generator(0), ol.generator(1)
+
+    def g1(k):
+        return ol.pt_to_affine(0, ol.mul_scalar(0, g, pm.limbs(k % pm.R)))
+
+    def g2(k):
+        return ol.pt_to_affine(1, ol.mul_scalar(1, h, pm.limbs(k % pm.R)))
+
+    ic_k = [11, 22, 33, 44]
+    xs = [5, pm.R - 3, 123456789]
+    al, be, a, b = 7, 9, 1001, 2002
+    vkx = ic_k[0] + sum(x * k for x, k in zip(xs, ic_k[1:]))
+    c = (a * b - al * be - vkx) % pm.R
+    vk = dict(alpha1=g1(al), beta2=g2(be), gamma2=g2(1), delta2=g2(1), ic=[g1(k) for k in ic_k])
+    proof, bad = g1(a) + g2(b) + g1(c), g1(a) + g2(b) + g1(c + 1)
+    V = k16.VerifyingKey(ctx, vk)
+    gts = V.coop_gt([proof, bad], [xs, xs])
+    assert gts[0].tobytes() == _check_gt(vk, proof, xs) == ol.pairing(vk["alpha1"], vk["beta2"])
+    assert gts[1].tobytes() == _check_gt(vk, bad, xs)
+    assert V.verify_batch([proof, bad, proof], [xs, xs, [xs[0], xs[1], xs[2] + 1]]) == [True, False, False]
+    # vk_x at infinity (x chosen so that IC[0] + x IC[1] = O with the other inputs zero): left to the general path
+    x0 = (-ic_k[0] * pow(ic_k[1], -1, pm.R)) % pm.R
+    assert V.verify_batch([proof], [[x0, 0, 0]]) == [ol.groth16_verify(vk, proof, [x0, 0, 0])]
+    V.close()
