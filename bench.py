@@ -47,7 +47,8 @@ R_MOD = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 ALGO_BYTES_PER_POINT = 64 + 32  # G1 MSM = n x (64 B affine point + 32 B scalar)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MODMUL_PER_PAIR = 10            # SURVEY 8(d) secondary figure: one mixed add (8M + 2S) per (point, window) pair
-MODMUL_PEAK_G = 174.3           # measured on MI355X: radix-2^29 Montgomery multiply, all CUs (profiles/r02/ubench_fmul29.log)
+MODMUL_PEAK_G = 174.3           # measured on MI355X: radix-2^29 Montgomery multiply (fmul29 chains of tools/ubench.hip, 8 blocks
+                                # per CU), all CUs: profiles/r02/ubench_instruction_rates.log
 KEYLESS = dict(n_vars=1343588, n_public=1, domain=1 << 21, n_coefs=8300000)   # circuit/README.md:77-83, SURVEY 8(d)
 
 
@@ -108,6 +109,27 @@ def scalar_times_g(ctx, k16, k):
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one (os.cpu_count() reports
+    the machine's cores even inside a container that is allowed a few of them -- 64 OpenMP threads on 16 allowed cores is
+    what made round 2's CPU baseline scale so badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(n_sample, scalars):
     """Times the CPU oracle (port of the reference's ParallelMultiexp) on the first n_sample points."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -115,21 +137,31 @@ def cpu_baseline(n_sample, scalars):
 
     # the port parallelises over (window, point slice) pairs like the reference's TBB loop; at 2^20 points it has 16 windows
     # x 4 slices = 64 tasks (more slices cost more in the pack step than they spread), so more threads would only idle
-    threads = min(os.cpu_count() or 1, 64)
+    avail = usable_cpus()
     bases = ol.gen_points(0, 0, n_sample)
     sc = np.ascontiguousarray(scalars[:n_sample])
-    ol.msm(0, bases[:4096], sc[:4096], nthreads=threads)  # warm-up
-    t0 = time.time()
-    ol.msm(0, bases, sc, nthreads=threads)
-    dt = time.time() - t0
+    ol.msm(0, bases[:4096], sc[:4096], nthreads=min(avail, 16))  # warm-up
+    # at 2^20 points the port has 16 windows x 4 point slices = 64 tasks (more slices cost more in the pack step than they
+    # spread): 16, 32 and 64 threads are tried (as far as the host allows) and the best is reported with ITS thread count
+    best = None
+    for threads in sorted({min(avail, t) for t in (16, 32, 64)}):
+        t0 = time.time()
+        ol.msm(0, bases, sc, nthreads=threads)
+        dt = time.time() - t0
+        if best is None or n_sample / dt > best[0]:
+            best = (n_sample / dt, threads, dt)
+    value, threads, dt = best
     return {
-        "value": n_sample / dt,
+        "value": value,
         "unit": "points/s",
         "cores": threads,
+        "usable_cpus": avail,
+        "points_per_s_per_core": value / threads,
+        "reference_single_thread_anchor": "36-37 k points/s/core (SURVEY section 6: the reference's generic backend, one thread)",
         "kind": "port",
-        "sample": "first 2^%d points of the same workload, %.1f s wall, oracle/bn254_ref.c (gcc -O2, OpenMP over "
-                  "windows x point slices, per-task bucket arrays + pack as multiexp.cpp:46-130)"
-                  % (int(np.log2(n_sample)), dt),
+        "sample": "first 2^%d points of the same workload, %.1f s wall at the best of 16 / 32 / 64 threads (of %d usable CPUs), "
+                  "oracle/bn254_ref.c (gcc -O2, OpenMP over windows x point slices, per-task bucket arrays + pack as "
+                  "multiexp.cpp:46-130)" % (int(np.log2(n_sample)), dt, avail),
     }
 
 
@@ -347,7 +379,24 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             c.close()
     out = None
     if rank == 0:
-        out = {"proofs_per_s": world * proofs / elapsed, "p50_ms": float(np.median(lat)),
+        p50 = float(np.median(lat))
+        # SURVEY 8(d) for the full proof.  Multiplications (254-bit modular, the unit that bounds the path): H MSM n x 13
+        # digit positions x 10; six transforms of N/2 log2 N butterflies + ~5 N pointwise; witness MSMs by the expected
+        # non-zero digits of the 90 / 8 / 2 % witness mix at c = 13 (0.93 per wire; B1 / B2 have half (0,0) rows; a G2
+        # mixed add is 10 Fq2 = 30 Fq multiplications); bucket reductions 2 full adds (14) per bucket; SpMV one per coefficient.
+        logN = int(np.log2(N))
+        mm = {"h_msm": N * 13 * 10, "ntt_and_pointwise": 6 * (N // 2) * logN + 5 * N,
+              "witness_msm_g1": int(n_vars * 0.93 * (1 + 0.5 + 1) * 10), "witness_msm_g2": int(n_vars * 0.93 * 0.5 * 30),
+              "bucket_reductions": (1 << 19) * 2 * 14 + 21 * 4096 * 2 * 14 * (3 + 3), "spmv": n_coefs}
+        mm_total = sum(mm.values())
+        hbm_bytes = (n_vars * (64 + 64 + 128 + 64) + N * 64) + n_vars * 32 + N * 32 + 6 * 2 * 32 * N + 44 * n_coefs + 5 * 3 * 32 * N
+        roof = {"modmul_per_proof": mm_total, "modmul_breakdown": mm,
+                "alu_frac": mm_total / (p50 * 1e-3) / 1e9 / MODMUL_PEAK_G, "alu_peak_g_modmul_s": MODMUL_PEAK_G,
+                "hbm_bytes_per_proof": hbm_bytes, "hbm_frac": hbm_bytes / (p50 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "basis": "algorithmic work of one proof (SURVEY 8(d)) over the p50 latency of one proof at a time; the path is "
+                         "integer-multiply-issue bound (alu_frac is the figure to move), hbm_frac is reported because "
+                         "BASELINE.json's bound is HBM"}
+        out = {"proofs_per_s": world * proofs / elapsed, "p50_ms": p50, "roofline": roof,
                "p99_ms": float(np.percentile(lat, 99)), "proofs": world * proofs, "entry": "k16_prover_prove_mem",
                "n_vars": n_vars, "domain": N, "n_coefs": n_coefs, "n_public": 1,
                "key": "synthetic, Keyless shape (the real zkey is not available offline); one resident copy per GPU",
@@ -367,7 +416,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             # the GPU's, and the byte-for-byte check of the GPU proof
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as ol
-            threads = min(os.cpu_count() or 1, 96)
+            threads = min(usable_cpus(), 96)
             t0 = time.time()
             want = ol.prove_files(zpath, wpath, r, s, nthreads=threads)
             cpu_s = time.time() - t0
@@ -377,6 +426,30 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             if got != want:
                 raise SystemExit("bench.py: GPU proof differs from the CPU oracle's")
         os.unlink(wpath)
+        try:
+            # the service's sequence: prove, then verify THAT proof before releasing it (prover_handler.rs:329-336).  The
+            # verification's cost does not depend on the circuit or on the proof being valid (3 Miller loops + one final
+            # exponentiation; one public input like Keyless): a toy-key proof stands in for the check of the synthetic key's.
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import groth16_io as gio
+            toy = os.path.join(ROOT, "tests", "golden", "toy")
+            V = k16.VerifyingKey(ctx, gio.vk_from_json(os.path.join(toy, "toy_vk.json")))
+            tp = k16.Prover(ctx, os.path.join(toy, "toy_1.zkey"))
+            toy_proof = gio.proof_from_json(tp.prove_file(os.path.join(toy, "toy.wtns")))
+            tp.close()
+            assert V.verify_batch([toy_proof], [[2]]) == [True]
+            both = []
+            for i in range(min(proofs, 12)):
+                t1 = time.perf_counter()
+                prover.prove_mem(wits[i % len(wits)])
+                ok = V.verify_batch([toy_proof], [[2]])
+                both.append((time.perf_counter() - t1) * 1e3)
+                assert ok == [True]
+            out["p50_with_verify_ms"] = float(np.median(both))
+            V.close()
+        except Exception as e:
+            out["p50_with_verify_ms"] = None
+            out["p50_with_verify_error"] = repr(e)
         try:
             out["verify"] = verify_leg(ctx, k16, check_with_oracle)
         except SystemExit:
@@ -406,6 +479,52 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def cold_probe_child(args):
+    """A FRESH process, no prewarm and no warm-up steps: the first MSM (workspace allocation, code objects, idle clocks) and
+    the average of the first 20, pipelined exactly like the timed region.  What a service sees right after start-up; the
+    headline figure is the steady state after bench.py's prewarm (`prewarm_steps`)."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import k16
+    ctx = k16.Context(0)
+    ctx.set_option(k16.OPT_PIPELINED_MSM, 1)
+    n = 1 << args.log2n
+    d_bases = ctx.synth_points(k16.G1, 0, n)
+    d_scalars = ctx.to_device(uniform_scalars(n, seed=0xD1B5))
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.set_lane(0)
+    ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
+    ctx.msm_finish(k16.G1)
+    first = (time.perf_counter() - t0) * 1e3
+    depth, steps, lane = 4, 20, 1
+    t0 = time.perf_counter()
+    for k in range(min(depth - 1, steps)):
+        ctx.set_lane(lane)
+        lane = (lane + 1) % depth
+        ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
+    for k in range(steps):
+        if k + depth - 1 < steps:
+            ctx.set_lane(lane)
+            lane = (lane + 1) % depth
+            ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
+        ctx.msm_finish(k16.G1)
+    per = (time.perf_counter() - t0) * 1e3 / steps
+    print(json.dumps({"first_step_ms": first, "ms_per_step_first20": per,
+                      "note": "fresh process, no prewarm, no warm-up; steps 2..21 pipelined four deep like the timed region"}), flush=True)
+    ctx.close()
+    return 0
+
+
+def cold_probe(args):
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-probe", "--log2n", str(args.log2n)],
+                             capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-300:]}
+    except Exception as e:   # a report, never the measured path
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -417,7 +536,10 @@ def main():
     ap.add_argument("--proofs", type=int, default=20, help="full Keyless-shape proofs per rank in the proof leg (0: skip it)")
     ap.add_argument("--proof-scale", type=float, default=1.0, help="shrink the synthetic circuit (1.0 = Keyless shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cold-probe", action="store_true", help=argparse.SUPPRESS)   # child of the main run, see cold_probe()
     args = ap.parse_args()
+    if args.cold_probe:
+        return cold_probe_child(args)
 
     n_gpus = max(args.gpus, 1)
     if "WORLD_SIZE" not in os.environ and n_gpus > 1:
@@ -427,6 +549,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != n_gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (n_gpus, world))
+
+    # the cold figures come from a child process that runs (and ends) before this one touches the GPU
+    cold = cold_probe(args) if (world == 1 and args.mode == "weak" and not os.environ.get("K16_BENCH_NO_COLD")) else None
 
     # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Four MSM lanes fill
     # them; with torch.distributed the RCCL stream would have to share one with a lane (measured at world size 1:
@@ -697,6 +822,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "prewarm_steps": prewarm,
+            "cold": cold,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
@@ -734,6 +860,9 @@ def main():
                     "achieved": pts_per_launch * 16 * MODMUL_PER_PAIR / (iso * 1e-3) / 1e9 if iso > 0 else None,
                     "peak": MODMUL_PEAK_G,
                     "frac": pts_per_launch * 16 * MODMUL_PER_PAIR / (iso * 1e-3) / 1e9 / MODMUL_PEAK_G if iso > 0 else None,
+                    "frac_step": pts_per_launch * 16 * MODMUL_PER_PAIR / (elapsed / args.steps) / 1e9 / MODMUL_PEAK_G / (world if not strong else 1),
+                    "frac_step_basis": "the same algorithmic multiplications over the whole STEP (ms_per_step: sort, accumulation, "
+                                       "fold, weighted sum, host combine of one MSM per lane, four lanes pipelined), per GPU",
                     "basis": "algorithmic 10 modmul x n x 16 windows per launch / kernel_ms_isolated; peak = measured "
                              "v_mad_u64_u32-bound multiply rate of the radix-2^29 field (no MFMA path exists for 254-bit integers)",
                 },
