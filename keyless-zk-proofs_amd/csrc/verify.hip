@@ -33,6 +33,9 @@ struct k16_vk {
     G1Aff*      d_wtab    = nullptr; // [(n_ic - 1) * 64 windows][16 digits]: digit * 16^window * IC[j + 1]
     Fq*         d_target  = nullptr; // e(alpha, beta), 12 canonical values
     uint32_t    n_chunks = 0, chunk_words = 0, lds_bytes = 0;
+    // device buffers of the small-batch (latency) case, allocated once: hipMalloc / hipFree per call cost more than 0.1 ms
+    static constexpr uint64_t SMALL_N = 64;
+    uint8_t *   d_small_pr = nullptr, *d_small_in = nullptr, *d_small_st = nullptr;
 };
 
 namespace {
@@ -115,7 +118,7 @@ struct CoopDev {
     uint32_t        n_chunks, chunk_words, n_const, in_base, n_slots, target_const;
     uint32_t        out_slot[12];
 };
-constexpr uint32_t COOP_CHUNK_BYTES = 32768;
+constexpr uint32_t COOP_CHUNK_BYTES = 24576;
 
 __device__ __forceinline__ Fq9 coop_ld9(const uint32_t* slots, uint32_t s)
 {
@@ -142,7 +145,7 @@ __device__ __forceinline__ T coop_shfl_down(const T& v, unsigned delta)
 }
 
 // status[i]: 0 rejected, 1 accepted, 2 "not decided here" (vk_x is the point at infinity: the general path decides)
-__global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* __restrict__ ctab9, const G1Aff* __restrict__ wtab,
+__global__ void __launch_bounds__(128) k_verify_coop(CoopDev D, const uint32_t* __restrict__ ctab9, const G1Aff* __restrict__ wtab,
                                                     const G1Aff* __restrict__ ic, uint32_t n_ic,
                                                     const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ inputs,
                                                     const Fq* __restrict__ target, uint8_t* __restrict__ status,
@@ -156,10 +159,30 @@ __global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* _
     };
     stamp(0);
     extern __shared__ uint32_t coop_lds[];
+    // TWO wavefronts: wave 0 computes; wave 1 is the LOADER -- it stages chunk c + 1 of the program into the other half of
+    // the staging buffer while wave 0 executes chunk c (the ~70 chunk loads, ~4 us each, used to sit between the chunks)
     uint32_t*      slots = coop_lds;
-    uint32_t*      buf   = coop_lds + ((D.n_slots * 9 + 3) & ~3u);
-    const unsigned lane  = threadIdx.x;
+    uint32_t*      buf0  = coop_lds + ((D.n_slots * 9 + 3) & ~3u);
+    const unsigned lane  = threadIdx.x & 63;
+    const bool     loader = threadIdx.x >= 64;
     const uint64_t pi    = blockIdx.x;
+    uint32_t*      ctab  = buf0 + 2 * D.chunk_words;
+    auto stage_chunk = [&](uint32_t c) { // by the 64 lanes of ONE wave; chunk table already in LDS (or read from global for c = 0)
+        const uint32_t s0 = D.chunks[4 * c], ns = D.chunks[4 * c + 1], tb = D.chunks[4 * c + 2], nt = D.chunks[4 * c + 3];
+        uint32_t*      b  = buf0 + (c & 1) * D.chunk_words;
+        const uint4*   wsrc = reinterpret_cast<const uint4*>(D.words + (size_t)s0 * 64);
+        uint4*         wdst = reinterpret_cast<uint4*>(b);
+        for (uint32_t k = lane; k < ns * 32; k += 64) wdst[k] = wsrc[k];
+        for (uint32_t k = lane; k < nt; k += 64) b[ns * 128 + k] = D.terms[tb + k];
+        uint32_t* hd = b + ns * 128 + ((nt + 3) & ~3u);
+        for (uint32_t k = lane; k < ns; k += 64) hd[k] = D.hdr[s0 + k];
+    };
+    if (loader) {
+        for (uint32_t k = lane; k < D.n_chunks * 4; k += 64) ctab[k] = D.chunks[k];
+        stage_chunk(0);
+    }
+    uint32_t undecided = 0;
+    if (!loader) {
     // ---- constants of the key -> slots [0, n_const)
     {
         const uint4* csrc = reinterpret_cast<const uint4*>(ctab9); // (table padded to a multiple of 4 words by the host)
@@ -181,7 +204,6 @@ __global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* _
         G1Xyzz o = coop_shfl_down(acc, d); // (lanes >= 64 - d read their own value: their sums are not used)
         acc      = padd(acc, o);
     }
-    uint32_t undecided = 0;
     Fq       vk_s[3] = {Fq::zero(), Fq::zero(), Fq::zero()}; // X ZZZ, Y ZZ, ZZ ZZZ: vk_x stays projective (verify_script.h)
     if (lane == 0) {
         acc = padd_mixed(acc, ic[0]);
@@ -194,10 +216,8 @@ __global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* _
         }
     }
     undecided = (uint32_t)__shfl((int)undecided, 0, 64);
-    if (undecided) { // uniform
-        if (lane == 0) status[pi] = 2;
-        return;
-    }
+    if (undecided && lane == 0) status[pi] = 2;
+    if (!undecided) {
     stamp(2);
     // ---- inputs -> slots: A.x A.y | B.x.a B.x.b B.y.a B.y.b | C.x C.y | vk_x as (X ZZZ, Y ZZ, ZZ ZZZ)
     {
@@ -217,38 +237,31 @@ __global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* _
         const Fq9 v9 = fq9_from_fq(v);
         if (lane < COOP_N_INPUTS) coop_st9(slots, D.in_base + lane, v9);
     }
+    } // !undecided
+    } // !loader
+    // the loader learns whether the proof is decided here through LDS
+    __shared__ uint32_t s_undecided;
+    if (threadIdx.x == 0) s_undecided = undecided;
     __syncthreads();
+    if (s_undecided) return; // both waves
     stamp(3);
     // ---- the program
     constexpr int64_t MASK = (1 << 29) - 1;
-    // the chunk table itself sits in LDS (behind the staging buffer): a chunk then costs one global round trip, not two
-    uint32_t* ctab = buf + D.chunk_words;
-    for (uint32_t k = lane; k < D.n_chunks * 4; k += 64) ctab[k] = D.chunks[k];
-    __syncthreads();
 #pragma clang loop unroll(disable)
     for (uint32_t c = 0; c < D.n_chunks; c++) {
-        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c]),
-                       ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 1]),
+        if (loader) { // stage the next chunk into the other half, then meet the compute wave at the barrier
+            if (c + 1 < D.n_chunks) stage_chunk(c + 1);
+            __syncthreads();
+            continue;
+        }
+        uint32_t* buf = buf0 + (c & 1) * D.chunk_words;
+        const uint32_t ns = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 1]),
                        tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 2]),
                        nt = (uint32_t)__builtin_amdgcn_readfirstlane((int)ctab[4 * c + 3]);
-        // one wavefront: LDS operations of a wave complete in program order, so a value stored by one lane is seen by the
-        // loads any lane issues later -- no barrier anywhere in this loop, only the compiler is told not to move LDS
-        // accesses across the step boundaries
+        // one wavefront computes: LDS operations of a wave complete in program order, so a value stored by one lane is seen
+        // by the loads any lane issues later -- no barrier inside a chunk
         uint32_t* hdrs = buf + ns * 128 + ((nt + 3) & ~3u);
         if (dbg) t_last = __builtin_amdgcn_s_memrealtime();
-        {
-            const uint4* wsrc = reinterpret_cast<const uint4*>(D.words + (size_t)s0 * 64);
-            uint4*       wdst = reinterpret_cast<uint4*>(buf);
-            for (uint32_t k = lane; k < ns * 32; k += 64) wdst[k] = wsrc[k];
-            for (uint32_t k = lane; k < nt; k += 64) buf[ns * 128 + k] = D.terms[tb + k];
-            for (uint32_t k = lane; k < ns; k += 64) hdrs[k] = D.hdr[s0 + k];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (dbg) {
-            const uint64_t now = __builtin_amdgcn_s_memrealtime();
-            tk[0] += now - t_last;
-            t_last = now;
-        }
         // the header and the instruction word of step s + 1 are loaded while step s executes (a lone wavefront has nobody to
         // hide an LDS round trip behind, and these two would head every step's dependency chain)
         uint32_t h_nx = hdrs[0], wlo_nx = buf[lane * 2], whi_nx = buf[lane * 2 + 1];
@@ -356,7 +369,22 @@ __global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* _
                 continue;
             } else { // CS_INV
                 r = fq9_zero();
-                if (valid) r = fq9_from_fq(finv_bgcd(fq9_to_fq(coop_ld9(slots, (wlo >> 14) & 0x3fff))));
+                // Fermat on the radix-2^29 field (254 squarings + ~127 multiplications at ~0.3 us each for a lone wave): faster
+                // here than the binary-GCD inversion of the canonical field (finv_bgcd: ~1000 dependent 8-limb steps)
+                if (valid) {
+                    const Fq9 x = coop_ld9(slots, (wlo >> 14) & 0x3fff); // < 6p: 2 * 6 <= 128, the multiply's operand bound
+                    r           = fq9_one();
+#pragma clang loop unroll(disable)
+                    for (int bit = 253; bit >= 0; bit--) { // x^(p - 2); p - 2 differs from p only in its lowest word
+                        r = fsqr9(r);
+                        const uint32_t ew = (bit >> 5) == 0 ? FqParams::P[0] - 2u
+                                                            : (bit >> 5) == 1 ? FqParams::P[1] : (bit >> 5) == 2 ? FqParams::P[2]
+                                                            : (bit >> 5) == 3 ? FqParams::P[3] : (bit >> 5) == 4 ? FqParams::P[4]
+                                                            : (bit >> 5) == 5 ? FqParams::P[5] : (bit >> 5) == 6 ? FqParams::P[6]
+                                                                                                                : FqParams::P[7];
+                        if ((ew >> (bit & 31)) & 1u) r = fmul9(r, x);
+                    }
+                }
             }
             if (valid) coop_st9(slots, dst, r); // (every lane's operand loads precede this store in program order)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -366,7 +394,9 @@ __global__ void __launch_bounds__(64) k_verify_coop(CoopDev D, const uint32_t* _
                 t_last = now;
             }
         }
+        __syncthreads(); // the loader has staged chunk c + 1 meanwhile
     }
+    if (loader) return;
     stamp(4);
     if (dbg && blockIdx.x == 0 && threadIdx.x == 0)
         for (int k = 0; k < 4; k++) dbg[5 + k] = tk[k];
@@ -434,7 +464,7 @@ extern "C" void k16_vk_destroy(k16_vk* vk)
     if (!vk) return;
     if (vk->ctx) (void)hipSetDevice(vk->ctx->device);
     void* bufs[] = {vk->d_ic, vk->d_g2, vk->d_K, vk->d_eab, vk->d_words, vk->d_terms, vk->d_hdr, vk->d_chunks, vk->d_ctab9,
-                    vk->d_wtab, vk->d_target};
+                    vk->d_wtab, vk->d_target, vk->d_small_pr, vk->d_small_in, vk->d_small_st};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete vk;
@@ -567,7 +597,7 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
             }
             vk->n_chunks  = (uint32_t)(chunks.size() / 4);
             vk->chunk_words = (max_chunk_words + 3) & ~3u;
-            vk->lds_bytes   = (((P->n_slots * 9 + 3) & ~3u) + vk->chunk_words + vk->n_chunks * 4) * 4;
+            vk->lds_bytes   = (((P->n_slots * 9 + 3) & ~3u) + 2 * vk->chunk_words + vk->n_chunks * 4) * 4; // two staging halves
             const Fq2* ev = &eab.c0.c0;
             Fq         target[12];
             for (int i = 0; i < 6; i++) {
@@ -584,6 +614,9 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
                        up((void**)&vk->d_ctab9, ctab9.data(), ctab9.size() * 4) &&
                        up((void**)&vk->d_wtab, wtab.data(), wtab.size() * sizeof(G1Aff)) &&
                        up((void**)&vk->d_target, target, sizeof target) &&
+                       hipMalloc((void**)&vk->d_small_pr, k16_vk::SMALL_N * 256) == hipSuccess &&
+                       hipMalloc((void**)&vk->d_small_in, std::max<size_t>(k16_vk::SMALL_N * (n_ic - 1) * 32, 16)) == hipSuccess &&
+                       hipMalloc((void**)&vk->d_small_st, k16_vk::SMALL_N) == hipSuccess &&
                        hipFuncSetAttribute((const void*)k_verify_coop, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)vk->lds_bytes) == hipSuccess;
             if (!vk->coop) (void)hipGetLastError();
@@ -603,9 +636,15 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
     uint8_t *    d_pr = nullptr, *d_in = nullptr, *d_st = nullptr;
     Fq*          d_gt = nullptr;
     const size_t in_bytes = (size_t)n * (vk->n_ic - 1) * 32;
-    K16_HIP(ctx, tmp.alloc((void**)&d_pr, (size_t)n * 256));
-    K16_HIP(ctx, tmp.alloc((void**)&d_in, in_bytes));
-    K16_HIP(ctx, tmp.alloc((void**)&d_st, n));
+    if (n <= k16_vk::SMALL_N) { // the latency case: buffers of the key, no allocation
+        d_pr = vk->d_small_pr;
+        d_in = vk->d_small_in;
+        d_st = vk->d_small_st;
+    } else {
+        K16_HIP(ctx, tmp.alloc((void**)&d_pr, (size_t)n * 256));
+        K16_HIP(ctx, tmp.alloc((void**)&d_in, in_bytes));
+        K16_HIP(ctx, tmp.alloc((void**)&d_st, n));
+    }
     if (h_gt) K16_HIP(ctx, tmp.alloc((void**)&d_gt, (size_t)n * 12 * sizeof(Fq)));
     K16_HIP(ctx, hipMemcpyAsync(d_pr, h_proofs, (size_t)n * 256, hipMemcpyHostToDevice, st));
     if (in_bytes) K16_HIP(ctx, hipMemcpyAsync(d_in, h_inputs, in_bytes, hipMemcpyHostToDevice, st));
@@ -625,7 +664,7 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
     static const bool trace = getenv("K16_VERIFY_COOP_TRACE") != nullptr;
     uint64_t*         d_dbg = nullptr;
     if (trace) K16_HIP(ctx, tmp.alloc((void**)&d_dbg, 16 * 8));
-    hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(64), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic, vk->n_ic,
+    hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(128), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic, vk->n_ic,
                        d_pr, d_in, vk->d_target, d_st, d_gt, d_dbg);
     K16_HIP(ctx, hipGetLastError());
     if (trace) {

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects every measurement DESIGN.md / README quote for this round on the GPU box into gpurun_out/r02/ (copy the
-# summaries into profiles/r02/ afterwards).  Run through gpurun from the repository root.
+# Collects every measurement DESIGN.md / README quote for this round on the GPU box into gpurun_out/r03/ (copy the
+# summaries into profiles/r03/ afterwards).  Run through gpurun from the repository root.
 set -u
-O=gpurun_out/r02
+O=gpurun_out/r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # 1. the driver's command, plain
@@ -21,7 +21,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/proof_stats -- python
 # 6. the multi-GPU code path on this one GPU: RCCL exchange forced at world size 1, and the strong-scaling leg (one 2^26 MSM)
 K16_BENCH_FORCE_DIST=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 40 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_force_dist_world1.json 2> $O/bench_force_dist_world1.err
 python3 bench.py --mode strong --total-log2n 26 --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > $O/bench_strong_2p26_1gpu.json 2> $O/bench_strong_2p26_1gpu.err
-python3 bench.py --gpus 2 --steps 2 --warmup 1 --proofs 0 > $O/bench_gpus2_on_1gpu_box.out 2>&1; echo "rc=$?" >> $O/bench_gpus2_on_1gpu_box.out
+K16_BENCH_SHARE_GPU=1 K16_BENCH_PREWARM=2 python3 bench.py --gpus 2 --steps 4 --warmup 1 --log2n 20 --proofs 0 --no-cpu-baseline > $O/bench_2ranks_shared_gpu_weak.json 2> $O/bench_2ranks_shared_gpu_weak.err
+K16_BENCH_SHARE_GPU=1 K16_BENCH_PREWARM=2 python3 bench.py --gpus 2 --mode strong --total-log2n 24 --steps 2 --warmup 1 --proofs 0 --no-cpu-baseline > $O/bench_2ranks_shared_gpu_strong.json 2> $O/bench_2ranks_shared_gpu_strong.err
 # 7. verifier
 python3 tools/bench_verify.py > $O/verify.json 2> $O/verify.err
 # 8. BASELINE config 4 on one GPU: a wave of proofs of a valid synthetic key from a prover pool, one batched verification
@@ -31,4 +32,12 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/k16_tl -- python3 tools/ben
 python3 tools/proof_timeline.py /tmp/k16_tl 2 > $O/proof_timeline.txt 2>> $O/proof_timeline.err
 python3 tools/fixed_base_timing.py 21 8 > $O/fixed_base_h_msm.log 2>&1
 python3 tools/ntt_timing.py 21 30 > $O/ntt_2p21.log 2>&1
+ls -la $O
+# 10. round 3: sort lab (per-kernel averages of the product's bucket sort), verifier trace, PMC write traffic of the sort
+tools/lab/sortlab 20 16 0 uniform 20 check > $O/sortlab_2p20_c16.log 2>&1
+tools/lab/sortlab 21 20 1 uniform 20 check > $O/sortlab_2p21_flat20.log 2>&1
+tools/lab/prof.sh r03s16 tools/lab/sortlab 20 16 0 uniform 20 > $O/sortlab_2p20_c16_kernels.txt 2>&1
+tools/lab/prof.sh r03sH tools/lab/sortlab 21 20 1 uniform 20 > $O/sortlab_2p21_flat20_kernels.txt 2>&1
+tools/lab/pmc.sh r03w16 WRITE_SIZE tools/lab/sortlab 20 16 0 uniform 3 > $O/sortlab_2p20_c16_WRITE_SIZE.txt 2>&1
+K16_VERIFY_COOP_TRACE=1 python3 tools/bench_verify.py > $O/verify.json 2> $O/verify_coop_trace.log
 ls -la $O
