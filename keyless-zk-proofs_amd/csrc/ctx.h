@@ -142,6 +142,7 @@ struct k16_ctx {
     // every kernel of the bucket sort in <= 32 VGPRs, so that it is resident BESIDE another lane's bucket accumulation
     // (msm_kernels.inc, "lean sort"); set with K16_OPT_PIPELINED_MSM, or K16_LEAN_SORT=0/1
     bool        lean_sort     = false;
+    bool        wc_sort       = false; // K16_WC_SORT: write-combining scatter pass of the partition (k_part_wc)
     unsigned    acc_dyn_grid  = 0; // K16_ACC_DYN: persistent accumulate grid of this many workgroups with dynamic chunk fetch
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;

@@ -73,6 +73,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (const char* e = getenv("K16_ACC_FENCE")) c->acc_fence_mode = atoi(e);
     if (const char* e = getenv("K16_ACC_GRID")) c->acc_grid_cap = (unsigned)std::max(0, atoi(e));
     if (const char* e = getenv("K16_LEAN_SORT")) c->lean_sort = atoi(e) != 0;
+    if (const char* e = getenv("K16_WC_SORT")) c->wc_sort = atoi(e) != 0;
     if (const char* e = getenv("K16_ACC_DYN")) c->acc_dyn_grid = (unsigned)std::max(0, atoi(e));
     if (const char* e = getenv("K16_ACC_LDS")) c->acc_lds_bytes = (unsigned)std::min(65536, std::max(0, atoi(e)));
     if (c->graphs_on && c->acc_fence_mode != 0) {

@@ -145,12 +145,14 @@ __device__ __forceinline__ T coop_shfl_down(const T& v, unsigned delta)
 }
 
 // status[i]: 0 rejected, 1 accepted, 2 "not decided here" (vk_x is the point at infinity: the general path decides)
+template <bool DBG>
 __global__ void __launch_bounds__(128) k_verify_coop(CoopDev D, const uint32_t* __restrict__ ctab9, const G1Aff* __restrict__ wtab,
                                                     const G1Aff* __restrict__ ic, uint32_t n_ic,
                                                     const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ inputs,
                                                     const Fq* __restrict__ target, uint8_t* __restrict__ status,
-                                                    Fq* __restrict__ gt_out, uint64_t* __restrict__ dbg)
+                                                    Fq* __restrict__ gt_out, uint64_t* __restrict__ dbg_ptr)
 {
+    uint64_t* const dbg = DBG ? dbg_ptr : nullptr; // (compile-time null in the production instantiation: no timing code)
     // dbg (K16_VERIFY_COOP_TRACE=1, proof 0 only): 100 MHz time stamps -- start, constants copied, vk_x done, inputs stored,
     // program done -- then the ticks spent staging chunks and in multiply / linear / inversion steps
     uint64_t tk[4] = {0, 0, 0, 0}, t_last = 0;
@@ -617,7 +619,9 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
                        hipMalloc((void**)&vk->d_small_pr, k16_vk::SMALL_N * 256) == hipSuccess &&
                        hipMalloc((void**)&vk->d_small_in, std::max<size_t>(k16_vk::SMALL_N * (n_ic - 1) * 32, 16)) == hipSuccess &&
                        hipMalloc((void**)&vk->d_small_st, k16_vk::SMALL_N) == hipSuccess &&
-                       hipFuncSetAttribute((const void*)k_verify_coop, hipFuncAttributeMaxDynamicSharedMemorySize,
+                       hipFuncSetAttribute((const void*)k_verify_coop<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)vk->lds_bytes) == hipSuccess &&
+                       hipFuncSetAttribute((const void*)k_verify_coop<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)vk->lds_bytes) == hipSuccess;
             if (!vk->coop) (void)hipGetLastError();
         }
@@ -646,8 +650,6 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
         K16_HIP(ctx, tmp.alloc((void**)&d_st, n));
     }
     if (h_gt) K16_HIP(ctx, tmp.alloc((void**)&d_gt, (size_t)n * 12 * sizeof(Fq)));
-    K16_HIP(ctx, hipMemcpyAsync(d_pr, h_proofs, (size_t)n * 256, hipMemcpyHostToDevice, st));
-    if (in_bytes) K16_HIP(ctx, hipMemcpyAsync(d_in, h_inputs, in_bytes, hipMemcpyHostToDevice, st));
     const CoopProgram* P = coop_program();
     CoopDev            D;
     D.words = vk->d_words;
@@ -664,8 +666,29 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
     static const bool trace = getenv("K16_VERIFY_COOP_TRACE") != nullptr;
     uint64_t*         d_dbg = nullptr;
     if (trace) K16_HIP(ctx, tmp.alloc((void**)&d_dbg, 16 * 8));
-    hipLaunchKernelGGL(k_verify_coop, dim3((unsigned)n), dim3(128), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic, vk->n_ic,
-                       d_pr, d_in, vk->d_target, d_st, d_gt, d_dbg);
+    // The latency case (n <= 64, no GT output): inputs and flags go through the context's pinned, device-mapped staging
+    // area (its last 64 KB) -- no copy commands at all, the call is one launch and one stream wait.
+    const bool     mapped = !h_gt && n <= k16_vk::SMALL_N && in_bytes <= 32768;
+    uint8_t*       hp     = (uint8_t*)ctx->pinned + (size_t)k16_ctx::PEND_SLOTS * k16_ctx::SLOT_BYTES;
+    const uint8_t* dp     = (const uint8_t*)ctx->pinned_dev + (size_t)k16_ctx::PEND_SLOTS * k16_ctx::SLOT_BYTES;
+    const uint8_t *k_pr = d_pr, *k_in = d_in;
+    uint8_t*       k_st = d_st;
+    if (mapped) {
+        memcpy(hp, h_proofs, (size_t)n * 256);
+        if (in_bytes) memcpy(hp + 16384, h_inputs, in_bytes);
+        k_pr = dp;
+        k_in = dp + 16384;
+        k_st = (uint8_t*)dp + 49152;
+    } else {
+        K16_HIP(ctx, hipMemcpyAsync(d_pr, h_proofs, (size_t)n * 256, hipMemcpyHostToDevice, st));
+        if (in_bytes) K16_HIP(ctx, hipMemcpyAsync(d_in, h_inputs, in_bytes, hipMemcpyHostToDevice, st));
+    }
+    if (trace)
+        hipLaunchKernelGGL(k_verify_coop<true>, dim3((unsigned)n), dim3(128), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic,
+                           vk->n_ic, k_pr, k_in, vk->d_target, k_st, d_gt, d_dbg);
+    else
+        hipLaunchKernelGGL(k_verify_coop<false>, dim3((unsigned)n), dim3(128), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic,
+                           vk->n_ic, k_pr, k_in, vk->d_target, k_st, d_gt, d_dbg);
     K16_HIP(ctx, hipGetLastError());
     if (trace) {
         uint64_t h[16];
@@ -675,9 +698,14 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
                 h[7] / 100.0, h[8] / 100.0);
     }
     std::vector<uint8_t> stt(n);
-    K16_HIP(ctx, hipMemcpyAsync(stt.data(), d_st, n, hipMemcpyDeviceToHost, st));
-    if (h_gt) K16_HIP(ctx, hipMemcpyAsync(h_gt, d_gt, (size_t)n * 12 * sizeof(Fq), hipMemcpyDeviceToHost, st));
-    K16_HIP(ctx, hipStreamSynchronize(st));
+    if (mapped) {
+        K16_HIP(ctx, hipStreamSynchronize(st));
+        memcpy(stt.data(), hp + 49152, n);
+    } else {
+        K16_HIP(ctx, hipMemcpyAsync(stt.data(), d_st, n, hipMemcpyDeviceToHost, st));
+        if (h_gt) K16_HIP(ctx, hipMemcpyAsync(h_gt, d_gt, (size_t)n * 12 * sizeof(Fq), hipMemcpyDeviceToHost, st));
+        K16_HIP(ctx, hipStreamSynchronize(st));
+    }
     for (uint64_t i = 0; i < n; i++)
         if (stt[i] > 1) return 1;
     if (h_ok) memcpy(h_ok, stt.data(), n);
