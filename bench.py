@@ -337,12 +337,12 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         allv = [None] * world
         dist.all_gather_object(allv, lat)
         lat = [x for l in allv for x in l]
-    # throughput mode (rank 0 reports, every rank runs it so that the GPUs stay symmetric): three provers -- own context,
-    # streams and resident key each -- share this GPU and prove concurrently from three threads, the deployment of
-    # INTEGRATION.md section 4 (K16_DEVICES=0,0,0 behind one FullProver).  One proof's upload / chain / H MSM then runs
+    # throughput mode (rank 0 reports, every rank runs it so that the GPUs stay symmetric): four provers -- own context,
+    # streams and resident key each -- share this GPU and prove concurrently from four threads, the deployment of
+    # INTEGRATION.md section 4 (K16_DEVICES=0,0,0,0 behind one FullProver).  One proof's upload / chain / H MSM then runs
     # under another's; latency per proof rises, proofs per second too.
     thr = None
-    n_conc = int(os.environ.get("K16_BENCH_PROVERS", "3"))
+    n_conc = int(os.environ.get("K16_BENCH_PROVERS", "4"))   # measured: 3 -> 158-161, 4 -> 172-177, 5 / 6 -> 172-175 proofs/s
     if n_conc > 1:
         import threading
         others = [k16.Context(ctx_device(ctx)) for _ in range(n_conc - 1)]

@@ -210,10 +210,12 @@ int  k16_prover_warmup_status(const k16_prover* p);
  * k16_verify_batch: h_proofs = n x 256 B (A | B | C), h_inputs = n x (n_ic - 1) x 32 B standard-form integers (any 256-bit
  * value; they act modulo r, as Fr::from_le_bytes_mod_order), out_ok[i] = 1 accept / 0 reject.  3n Miller loops and n final
  * exponentiations, one GPU lane each: a throughput path for batches (BASELINE config 4 releases 64 proofs per wave).
- * Like ark-groth16's verify_proof_with_prepared_inputs it does NOT test that A, B, C lie on the curve / in the r-torsion
- * (the service verifies its own prover's output; aptos-types validates foreign points when it deserialises them): a
- * caller that verifies proofs from elsewhere must validate the points first.  Points with a zero coordinate pair count as
- * the point at infinity (the pair then contributes 1, as ark-ec's multi_miller_loop skips it). */
+ * Input validation: a proof whose A / B / C has a coordinate >= p (a non-canonical encoding: A, A + p, A + 2p would
+ * otherwise be interchangeable) or does not lie on the curve (A, C) / the twist (B) is REJECTED (flag 0), as ark's
+ * deserialisation refuses it before verify_proof runs.  Membership of B in the r-torsion subgroup is NOT tested (the
+ * service verifies its own prover's output; aptos-types validates foreign points when it deserialises them): a caller that
+ * verifies proofs from elsewhere must do that first.  Points with a zero coordinate pair count as the point at infinity
+ * (the pair then contributes 1, as ark-ec's multi_miller_loop skips it). */
 typedef struct k16_vk k16_vk;
 int  k16_vk_create(k16_ctx* ctx, const void* alpha1_g1, const void* beta2_g2, const void* gamma2_g2, const void* delta2_g2,
                    const void* ic_g1, uint32_t n_ic, k16_vk** out);

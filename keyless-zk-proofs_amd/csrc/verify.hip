@@ -40,11 +40,38 @@ struct k16_vk {
 
 namespace {
 
+// Input validation (what ark's deserialisation does before verify_proof ever sees a point; round-2 advisor finding): every
+// coordinate must be a canonical field element (< p: otherwise A, A + p, A + 2p ... would be 2-3 encodings of one proof),
+// and A, C must lie on y^2 = x^3 + 3, B on the twist y^2 = x^3 + 3 / (9 + u).  The all-zero encoding of the point at
+// infinity passes (the pair then contributes 1).  A proof that fails is REJECTED (flag 0).  Membership of B in the
+// r-torsion subgroup is still the caller's duty (include/k16.h).
+__device__ __forceinline__ bool fq_canonical(const Fq& x)
+{
+    uint32_t borrow = 0; // x - p borrows  <=>  x < p
+#pragma unroll
+    for (int i = 0; i < 8; i++) borrow = (uint32_t)(((uint64_t)x.v[i] - FqParams::P[i] - borrow) >> 63);
+    return borrow != 0;
+}
+__device__ __forceinline__ bool g1_input_ok(const G1Aff& a)
+{
+    if (!fq_canonical(a.x) || !fq_canonical(a.y)) return false;
+    if (a.is_zero()) return true;
+    const Fq three = fadd(fadd(Fq::one(), Fq::one()), Fq::one());
+    return fsqr(a.y) == fadd(fmul(fsqr(a.x), a.x), three);
+}
+__device__ __forceinline__ bool g2_input_ok(const G2Aff& b, const Fq2& twist_b)
+{
+    if (!fq_canonical(b.x.a) || !fq_canonical(b.x.b) || !fq_canonical(b.y.a) || !fq_canonical(b.y.b)) return false;
+    if (b.is_zero()) return true;
+    return fsqr(b.y) == fadd(fmul(fsqr(b.x), b.x), twist_b);
+}
+
 // proof i: A (64 B) | B (128 B) | C (64 B), affine Montgomery.  Writes the three (P, Q) pairs of the check.
 __global__ void __launch_bounds__(64) k_verify_prepare(const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ inputs,
                                                        uint64_t n, uint32_t n_ic, const G1Aff* __restrict__ ic,
                                                        const G2Aff* __restrict__ neg_g2, G1Aff* __restrict__ P,
-                                                       G2Aff* __restrict__ Q)
+                                                       G2Aff* __restrict__ Q, const PairConsts* __restrict__ K,
+                                                       uint8_t* __restrict__ bad)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -54,6 +81,7 @@ __global__ void __launch_bounds__(64) k_verify_prepare(const uint8_t* __restrict
     memcpy(&a, pr, 64);
     memcpy(&b, pr + 64, 128);
     memcpy(&c, pr + 192, 64);
+    bad[i] = (g1_input_ok(a) && g1_input_ok(c) && g2_input_ok(b, K->twist_b)) ? 0 : 1;
     // prepare_inputs (ark-groth16 verifier.rs): g_ic = IC[0] + sum_j x_j * IC[j + 1]; x_j is a 256-bit integer in standard
     // form (the service passes Fr::from_le_bytes_mod_order, i.e. any representative works: G1 has order r)
     G1Xyzz acc = G1Xyzz::from_aff(ic[0]);
@@ -87,7 +115,8 @@ __global__ void __launch_bounds__(64) k_pair_miller(const G1Aff* __restrict__ P,
 // lane i: product of `per` consecutive Miller-loop values, final exponentiation, comparison with *target (if given)
 __global__ void __launch_bounds__(64) k_pair_final(const Fp12* __restrict__ f, uint64_t n, uint32_t per,
                                                    const PairConsts* __restrict__ K, const Fp12* __restrict__ target,
-                                                   uint8_t* __restrict__ ok, Fp12* __restrict__ gt)
+                                                   uint8_t* __restrict__ ok, Fp12* __restrict__ gt,
+                                                   const uint8_t* __restrict__ bad)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -103,7 +132,7 @@ __global__ void __launch_bounds__(64) k_pair_final(const Fp12* __restrict__ f, u
     if (gt) gt[i] = e;
     if (ok) {
         Fp12 t = *target;
-        ok[i]  = (good && f12_eq(e, t)) ? 1 : 0;
+        ok[i]  = (good && f12_eq(e, t) && !(bad && bad[i])) ? 1 : 0;
     }
 }
 
@@ -150,7 +179,8 @@ __global__ void __launch_bounds__(128) k_verify_coop(CoopDev D, const uint32_t* 
                                                     const G1Aff* __restrict__ ic, uint32_t n_ic,
                                                     const uint8_t* __restrict__ proofs, const uint8_t* __restrict__ inputs,
                                                     const Fq* __restrict__ target, uint8_t* __restrict__ status,
-                                                    Fq* __restrict__ gt_out, uint64_t* __restrict__ dbg_ptr)
+                                                    Fq* __restrict__ gt_out, uint64_t* __restrict__ dbg_ptr,
+                                                    const Fq2* __restrict__ twist_b)
 {
     uint64_t* const dbg = DBG ? dbg_ptr : nullptr; // (compile-time null in the production instantiation: no timing code)
     // dbg (K16_VERIFY_COOP_TRACE=1, proof 0 only): 100 MHz time stamps -- start, constants copied, vk_x done, inputs stored,
@@ -185,6 +215,33 @@ __global__ void __launch_bounds__(128) k_verify_coop(CoopDev D, const uint32_t* 
     }
     uint32_t undecided = 0;
     if (!loader) {
+    // ---- input validation (canonical coordinates, on the curve / the twist): an invalid proof is rejected here
+    {
+        bool ok_in = true;
+        if (lane == 0 || lane == 1) {
+            G1Aff a;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(proofs + pi * 256 + (lane == 0 ? 0 : 192));
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                a.x.v[k] = src[k];
+                a.y.v[k] = src[8 + k];
+            }
+            ok_in = g1_input_ok(a);
+        } else if (lane == 2) {
+            G2Aff b;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(proofs + pi * 256 + 64);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                b.x.a.v[k] = src[k];
+                b.x.b.v[k] = src[8 + k];
+                b.y.a.v[k] = src[16 + k];
+                b.y.b.v[k] = src[24 + k];
+            }
+            ok_in = g2_input_ok(b, *twist_b);
+        }
+        if (__ballot(ok_in) != ~0ull) undecided = 3; // decided: rejected
+    }
+    if (undecided == 0) {
     // ---- constants of the key -> slots [0, n_const)
     {
         const uint4* csrc = reinterpret_cast<const uint4*>(ctab9); // (table padded to a multiple of 4 words by the host)
@@ -240,6 +297,8 @@ __global__ void __launch_bounds__(128) k_verify_coop(CoopDev D, const uint32_t* 
         if (lane < COOP_N_INPUTS) coop_st9(slots, D.in_base + lane, v9);
     }
     } // !undecided
+    } // input valid
+    if (undecided == 3 && lane == 0) status[pi] = 0;
     } // !loader
     // the loader learns whether the proof is decided here through LDS
     __shared__ uint32_t s_undecided;
@@ -448,12 +507,12 @@ struct DevBufs {
 };
 
 int pairings_on_device(k16_ctx* ctx, const PairConsts* d_K, const G1Aff* d_P, const G2Aff* d_Q, uint64_t n, uint32_t per,
-                       const Fp12* d_target, uint8_t* d_ok, Fp12* d_gt, Fp12* d_f)
+                       const Fp12* d_target, uint8_t* d_ok, Fp12* d_gt, Fp12* d_f, const uint8_t* d_bad = nullptr)
 {
     hipStream_t st = ctx->stream;
     const uint64_t m = n * per;
     hipLaunchKernelGGL(k_pair_miller, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, d_P, d_Q, m, d_K, d_f);
-    hipLaunchKernelGGL(k_pair_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_f, n, per, d_K, d_target, d_ok, d_gt);
+    hipLaunchKernelGGL(k_pair_final, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_f, n, per, d_K, d_target, d_ok, d_gt, d_bad);
     K16_HIP(ctx, hipGetLastError());
     return K16_OK;
 }
@@ -685,10 +744,10 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
     }
     if (trace)
         hipLaunchKernelGGL(k_verify_coop<true>, dim3((unsigned)n), dim3(128), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic,
-                           vk->n_ic, k_pr, k_in, vk->d_target, k_st, d_gt, d_dbg);
+                           vk->n_ic, k_pr, k_in, vk->d_target, k_st, d_gt, d_dbg, &vk->d_K->twist_b);
     else
         hipLaunchKernelGGL(k_verify_coop<false>, dim3((unsigned)n), dim3(128), vk->lds_bytes, st, D, vk->d_ctab9, vk->d_wtab, vk->d_ic,
-                           vk->n_ic, k_pr, k_in, vk->d_target, k_st, d_gt, d_dbg);
+                           vk->n_ic, k_pr, k_in, vk->d_target, k_st, d_gt, d_dbg, &vk->d_K->twist_b);
     K16_HIP(ctx, hipGetLastError());
     if (trace) {
         uint64_t h[16];
@@ -768,9 +827,11 @@ extern "C" int k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_pr
     K16_HIP(ctx, tmp.alloc((void**)&d_f, (size_t)3 * n * sizeof(Fp12)));
     K16_HIP(ctx, hipMemcpyAsync(d_pr, h_proofs, (size_t)n * 256, hipMemcpyHostToDevice, st));
     if (in_bytes) K16_HIP(ctx, hipMemcpyAsync(d_in, h_inputs, in_bytes, hipMemcpyHostToDevice, st));
+    uint8_t* d_bad = nullptr;
+    K16_HIP(ctx, tmp.alloc((void**)&d_bad, n));
     hipLaunchKernelGGL(k_verify_prepare, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, d_pr, d_in, n, vk->n_ic, vk->d_ic,
-                       vk->d_g2, d_P, d_Q);
-    int rc = pairings_on_device(ctx, vk->d_K, d_P, d_Q, n, 3, vk->d_eab, d_ok, nullptr, d_f);
+                       vk->d_g2, d_P, d_Q, vk->d_K, d_bad);
+    int rc = pairings_on_device(ctx, vk->d_K, d_P, d_Q, n, 3, vk->d_eab, d_ok, nullptr, d_f, d_bad);
     if (rc) return rc;
     K16_HIP(ctx, hipMemcpyAsync(h_ok, d_ok, n, hipMemcpyDeviceToHost, st));
     K16_HIP(ctx, hipStreamSynchronize(st));

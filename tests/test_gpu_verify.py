@@ -280,3 +280,28 @@ def test_wave_cooperative_verifier_several_public_inputs(ctx):
     x0 = (-ic_k[0] * pow(ic_k[1], -1, pm.R)) % pm.R
     assert V.verify_batch([proof], [[x0, 0, 0]]) == [ol.groth16_verify(vk, proof, [x0, 0, 0])]
     V.close()
+
+
+def test_verifier_rejects_non_canonical_and_off_curve_points(ctx, toy_paths, monkeypatch):
+    """ark's deserialisation refuses non-canonical encodings and points off the curve before verify_proof sees them (round-2
+    advisor finding: A, A + p and A + 2p all fit 256 bits and verified identically, so proof bytes were malleable).  Both GPU
+    paths now reject them; the valid proof is still accepted."""
+    import k16
+    zkey, wtns, vkp = toy_paths
+    vk = gio.vk_from_json(vkp)
+    known = gio.proof_from_json(KNOWN_RS0)
+
+    def bump(proof, off, delta):
+        v = int.from_bytes(proof[off:off + 32], "little") + delta
+        return proof[:off] + (v % (1 << 256)).to_bytes(32, "little") + proof[off + 32:]
+
+    bad = [bump(known, 0, pm.Q), bump(known, 32, pm.Q), bump(known, 64, pm.Q), bump(known, 160, pm.Q), bump(known, 192, pm.Q),
+           bump(known, 0, 2 * pm.Q),           # A.x + p, A.y + p, B.x.a + p, B.y.b + p, C.x + p, A.x + 2p: same residues
+           bump(known, 32, 1), bump(known, 96, 1), bump(known, 224, 1)]   # off the curve / the twist
+    for no_coop in (False, True):
+        if no_coop:
+            monkeypatch.setenv("K16_VERIFY_NO_COOP", "1")
+        V = k16.VerifyingKey(ctx, vk)
+        assert V.verify_batch([known] + bad, [[2]] * (1 + len(bad))) == [True] + [False] * len(bad), no_coop
+        assert V.verify_batch([bad[0]], [[2]]) == [False]
+        V.close()
