@@ -21,7 +21,11 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <sched.h>
 #include <string>
+#include <thread>
 #include <vector>
 #include "ctx.h"
 #include "bn254_fq9.h"
@@ -192,6 +196,35 @@ __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr
     if (i < N) st_fr(&out[i], fr9_to_standard(frsub9(frmul9(ld_r9(&a[i]), ld_r9(&b[i])), ld_r9(&c[i]))));
 }
 
+// Witness upload in compact form.  A circom witness is n x 32 bytes of which ~98 % of the values are below 256 (bits and
+// bytes): 43 MB for the Keyless circuit, 0.78 ms of PCIe time during which the GPU has nothing to do.  The host (a few
+// threads, witness_pack below) splits it into one byte per wire + a list of the wide values (2.3 MB); this kernel rebuilds
+// the n x 32-byte array in HBM, reading both straight from pinned, device-mapped host memory.  Same bytes as the plain copy.
+__global__ void __launch_bounds__(256) k_wtns_expand_narrow(const uint8_t* __restrict__ narrow, Fr* __restrict__ out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4* d = reinterpret_cast<uint4*>(&out[i]);
+    d[0]     = make_uint4((uint32_t)narrow[i], 0u, 0u, 0u);
+    d[1]     = make_uint4(0u, 0u, 0u, 0u);
+}
+struct WideLists {
+    const uint32_t* idx[32];
+    const uint4*    val[32]; // 2 x uint4 per value
+    uint32_t        count[32];
+    uint32_t        n_lists;
+};
+__global__ void __launch_bounds__(256) k_wtns_expand_wide(WideLists L, Fr* __restrict__ out)
+{
+    const uint32_t t = blockIdx.y;
+    if (t >= L.n_lists) return;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < L.count[t]; j += gridDim.x * blockDim.x) {
+        uint4* d = reinterpret_cast<uint4*>(&out[L.idx[t][j]]);
+        d[0]     = L.val[t][2 * j];
+        d[1]     = L.val[t][2 * j + 1];
+    }
+}
+
 // ---------------------------------------------------------------- host helpers
 // fq.cpp:225-236 : fromMontgomery then base 10
 std::string fq_to_dec(const Fq& m)
@@ -284,7 +317,144 @@ struct k16_prover {
     hipEvent_t     ev_w = nullptr, ev_h = nullptr;
     std::vector<uint8_t> last_h;
     int warmup_rc = 0; // status of the create-time warm-up proof (k16_prover_warmup_status)
+    struct WitnessPacker* packer = nullptr; // compact witness upload (see k_wtns_expand_*); null: plain copy
 };
+
+// Host side of the compact upload: T threads (the caller + T - 1 pooled workers) each scan a contiguous range of the witness.
+struct WitnessPacker {
+    unsigned             n_threads = 0;
+    uint32_t             n_vars    = 0;
+    uint8_t*             h_narrow  = nullptr; // pinned, device-mapped: one byte per wire
+    uint32_t*            h_idx     = nullptr; // pinned: n_threads regions of `cap` wide-value indices
+    uint8_t*             h_val     = nullptr; //         ... and their 32-byte values
+    uint8_t *            d_narrow = nullptr;
+    uint32_t*            d_idx    = nullptr;
+    uint8_t*             d_val    = nullptr;
+    uint32_t             cap      = 0; // wide values a thread's region holds (a quarter of its range: beyond that, plain copy)
+    std::vector<uint32_t> count;
+    std::vector<uint8_t>  overflow;
+    // pool
+    std::vector<std::thread> workers;
+    std::mutex               mu;
+    std::condition_variable  cv_go, cv_done;
+    uint64_t                 gen = 0;
+    unsigned                 pending = 0;
+    bool                     quit = false;
+    const uint8_t*           src = nullptr;
+
+    void pack_range(unsigned t)
+    {
+        const uint64_t lo = (uint64_t)n_vars * t / n_threads, hi = (uint64_t)n_vars * (t + 1) / n_threads;
+        uint32_t*      ix = h_idx + (size_t)t * cap;
+        uint8_t*       vv = h_val + (size_t)t * cap * 32;
+        uint32_t       c = 0;
+        bool           ovf = false;
+        for (uint64_t i = lo; i < hi; i++) {
+            uint64_t w[4];
+            memcpy(w, src + i * 32, 32);
+            if (((w[0] >> 8) | w[1] | w[2] | w[3]) == 0) {
+                h_narrow[i] = (uint8_t)w[0];
+            } else {
+                h_narrow[i] = 0;
+                if (c < cap) {
+                    ix[c] = (uint32_t)i;
+                    memcpy(vv + (size_t)c * 32, w, 32);
+                    c++;
+                } else {
+                    ovf = true;
+                }
+            }
+        }
+        count[t]    = c;
+        overflow[t] = ovf;
+    }
+    void worker(unsigned t)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+            }
+            pack_range(t);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    // returns false when a range had more wide values than its region holds (the caller then copies the witness plainly)
+    bool pack(const void* witness)
+    {
+        src = (const uint8_t*)witness;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            pending = n_threads - 1;
+            gen++;
+        }
+        cv_go.notify_all();
+        pack_range(0);
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        for (unsigned t = 0; t < n_threads; t++)
+            if (overflow[t]) return false;
+        return true;
+    }
+    ~WitnessPacker()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (auto& w : workers) w.join();
+        if (h_narrow) (void)hipHostFree(h_narrow);
+        if (h_idx) (void)hipHostFree(h_idx);
+        if (h_val) (void)hipHostFree(h_val);
+    }
+};
+static unsigned packer_threads()
+{
+    if (const char* e = getenv("K16_UPLOAD_THREADS")) return (unsigned)std::max(0, std::min(32, atoi(e)));
+    cpu_set_t set;
+    unsigned  n = 1;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    return std::max(1u, std::min(12u, n * 3 / 4)); // three quarters of the CPUs the process may use, at most 12
+    // (measured on a 16-CPU box, Keyless shape: plain copy p50 7.0 ms; 4 threads 6.9-7.0; 8 threads 6.5; 12 threads 6.47)
+}
+static WitnessPacker* packer_create(uint32_t n_vars)
+{
+    const unsigned T = packer_threads();
+    if (T == 0 || n_vars < (1u << 16)) return nullptr; // small circuits: the plain copy is a few microseconds
+    WitnessPacker* w = new WitnessPacker();
+    w->n_threads     = T;
+    w->n_vars        = n_vars;
+    w->cap           = (n_vars / T) / 4 + 64;
+    w->count.assign(T, 0);
+    w->overflow.assign(T, 0);
+    const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (hipHostMalloc((void**)&w->h_narrow, n_vars, flags) != hipSuccess ||
+        hipHostMalloc((void**)&w->h_idx, (size_t)T * w->cap * 4, flags) != hipSuccess ||
+        hipHostMalloc((void**)&w->h_val, (size_t)T * w->cap * 32, flags) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&w->d_narrow, w->h_narrow, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&w->d_idx, w->h_idx, 0) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&w->d_val, w->h_val, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        delete w;
+        return nullptr;
+    }
+    try {
+        for (unsigned t = 1; t < T; t++) w->workers.emplace_back([w, t] { w->worker(t); });
+    } catch (...) { // no threads to be had: the plain copy still works
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
 
 static void prover_free(k16_prover* p)
 {
@@ -296,6 +466,7 @@ static void prover_free(k16_prover* p)
     if (p->st2) (void)hipStreamDestroy(p->st2);
     if (p->ev_w) (void)hipEventDestroy(p->ev_w);
     if (p->ev_h) (void)hipEventDestroy(p->ev_h);
+    delete p->packer;
     delete p;
 }
 
@@ -499,6 +670,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // workspaces, the lane streams and the code objects of every kernel come into being here instead of inside the first
     // request (35 ms instead of 8 through the facade).  Its outcome does not decide anything: a device that cannot prove
     // says so on the first real request.  Not under fault injection, whose counter counts requests.
+    p->packer = packer_create(p->n_vars);
 #ifdef K16_TESTING
     const bool fault_env = getenv("K16_FAULT_INJECT") != nullptr;
 #else
@@ -653,7 +825,24 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count());
     };
     K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
-    K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
+    if (p->packer && p->packer->pack(h_wtns)) {
+        WitnessPacker* w = p->packer;
+        WideLists      L;
+        L.n_lists = w->n_threads;
+        uint32_t most = 0;
+        for (unsigned t = 0; t < w->n_threads; t++) {
+            L.idx[t]   = w->d_idx + (size_t)t * w->cap;
+            L.val[t]   = reinterpret_cast<const uint4*>(w->d_val + (size_t)t * w->cap * 32);
+            L.count[t] = w->count[t];
+            most       = std::max(most, w->count[t]);
+        }
+        hipLaunchKernelGGL(k_wtns_expand_narrow, dim3((p->n_vars + 255) / 256), dim3(256), 0, st, w->d_narrow, p->d_wtns, p->n_vars);
+        if (most)
+            hipLaunchKernelGGL(k_wtns_expand_wide, dim3(std::min<uint32_t>((most + 255) / 256, 64), w->n_threads), dim3(256), 0, st, L, p->d_wtns);
+        K16_HIP(ctx, hipGetLastError());
+    } else {
+        K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
+    }
 
     // The reference overlaps the four witness MSMs with the a/b/c chain through std::async
     // (groth16.cpp:88-112 vs :116-275); here the chain (HBM-bound) runs on a second stream beside the
