@@ -105,11 +105,35 @@ K16_HD Aff<F> pneg(const Aff<F>& p)
     return Aff<F>{p.x, fneg(p.y)};
 }
 // curve.cpp:565-576
+// (host: ONE inversion, by the binary extended Euclid -- the three conversions at the end of a proof were six Fermat
+// inversions, ~0.1 ms on the critical path; the inverse is unique, so the result is the same canonical value)
+K16_HD Fq finv_once(const Fq& x)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return finv(x);
+#else
+    return finv_bgcd(x);
+#endif
+}
+K16_HD Fq2 finv_once(const Fq2& x)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+    return finv(x);
+#else
+    const Fq t = finv_bgcd(fadd(fsqr(x.a), fsqr(x.b))); // f2field.cpp:178-190: (a - bu) / (a^2 + b^2)
+    return Fq2{fmul(x.a, t), fneg(fmul(x.b, t))};
+#endif
+}
 template <class F>
 K16_HD Aff<F> to_affine(const Xyzz<F>& p)
 {
     if (p.is_zero()) return Aff<F>{F::zero(), F::zero()};
+#ifdef __HIP_DEVICE_COMPILE__
     return Aff<F>{fmul(p.x, finv(p.zz)), fmul(p.y, finv(p.zzz))};
+#else
+    const F t = finv_once(fmul(p.zz, p.zzz)); // 1 / zz = t zzz, 1 / zzz = t zz
+    return Aff<F>{fmul(p.x, fmul(t, p.zzz)), fmul(p.y, fmul(t, p.zz))};
+#endif
 }
 
 // Single scalar multiplication (Curve::mulByScalar, curve.hpp:195-207 -> exp.hpp:9-31): NAF walk,

@@ -13,6 +13,77 @@
 #include "bn254_curve.h"
 #include "bn254_fq9.h"
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <thread>
+
+// A few host threads for the two host-side loops that sit on a proof's critical path: packing the witness for the compact
+// upload (prover.hip) and combining the per-window partial sums of the last MSM (msm_api.hip).  Workers sleep on a
+// condition variable between jobs; run() hands out task numbers from an atomic counter, the caller takes part.
+struct k16_host_pool {
+    std::vector<std::thread>      workers;
+    std::mutex                    mu, run_mu;
+    std::condition_variable       cv_go, cv_done;
+    uint64_t                      gen = 0;
+    unsigned                      pending = 0;
+    bool                          quit = false;
+    std::function<void(unsigned)> job;
+    std::atomic<unsigned>         next{0};
+    unsigned                      n_tasks = 0;
+    explicit k16_host_pool(unsigned n_workers)
+    {
+        for (unsigned t = 0; t < n_workers; t++) workers.emplace_back([this] { loop(); });
+    }
+    unsigned width() const { return (unsigned)workers.size() + 1; }
+    void     drain()
+    {
+        for (unsigned t; (t = next.fetch_add(1)) < n_tasks;) job(t);
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void run(unsigned tasks, std::function<void(unsigned)> f) // f(task) for task in [0, tasks); returns when all are done
+    {
+        std::lock_guard<std::mutex> one(run_mu);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job     = std::move(f);
+            n_tasks = tasks;
+            next.store(0);
+            pending = (unsigned)workers.size();
+            gen++;
+        }
+        cv_go.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~k16_host_pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (auto& w : workers) w.join();
+    }
+};
+
 struct k16_devbuf {
     void*  p     = nullptr;
     size_t bytes = 0;
@@ -146,7 +217,14 @@ struct k16_ctx {
     unsigned    acc_dyn_grid  = 0; // K16_ACC_DYN: persistent accumulate grid of this many workgroups with dynamic chunk fetch
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
+    k16_host_pool*                    pool = nullptr; // created on first use (k16_ctx_pool), K16_HOST_THREADS wide
+    bool                              pool_tried = false;
+    // the per-window combine of an MSM's partial sums runs on the host pool only when asked to (the prover does for the H MSM,
+    // the last item on a proof's critical path; for MSMs whose combine overlaps GPU work, waking the pool only costs)
+    bool                              parallel_combine = false;
 };
+// the context's host thread pool, or nullptr (K16_HOST_THREADS=1, or no thread could be started): callers then loop serially
+k16_host_pool* k16_ctx_pool(k16_ctx* ctx);
 
 // Lane streams are created on first use: ROCm multiplexes a process's streams onto 4 hardware queues by default
 // (GPU_MAX_HW_QUEUES), so a stream that is never used must not take one from those that are -- the prover runs lanes

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <string>
 #include <vector>
+#include <functional>
 #include "ctx.h"
 #include "bn254_fq9.h"
 
@@ -36,21 +37,18 @@ unsigned choose_c(const k16_ctx* ctx, uint64_t n)
 // Host tail of the MSM: per window  val = T[nbits] + T[nbits+1] + M * sum_b 2^b T[b]  (msm_kernels.inc, K4),
 // then the Horner combine over windows (multiexp.cpp:236-242).
 template <class F>
-void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
+Xyzz<F> window_value_host(const Xyzz<F>* tw, unsigned nbits, unsigned mlog);
+template <class F>
+void window_values_host(k16_ctx* ctx, const Xyzz<F>* T, unsigned W, unsigned nbits, unsigned mlog, std::vector<Xyzz<F>>* out);
+template <class F>
+void horner_host(k16_ctx* ctx, const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
 {
+    std::vector<Xyzz<F>> val;
+    window_values_host<F>(ctx, T, W, nbits, mlog, &val);
     Xyzz<F> r = Xyzz<F>::zero();
     for (int w = (int)W - 1; w >= 0; w--) {
-        const Xyzz<F>* tw = T + (size_t)w * (nbits + 2);
-        Xyzz<F>        t  = Xyzz<F>::zero();
-        for (int b = (int)nbits - 1; b >= 0; b--) {
-            t = pdbl(t);
-            t = padd(t, tw[b]);
-        }
-        for (unsigned k = 0; k < mlog; k++) t = pdbl(t);
-        t = padd(t, tw[nbits]);
-        t = padd(t, tw[nbits + 1]); // + sum of all X: slot i' carries the weight i' + 1
         for (unsigned k = 0; k < c; k++) r = pdbl(r);
-        r = padd(r, t);
+        r = padd(r, val[w]);
     }
     *out = r;
 }
@@ -58,21 +56,49 @@ void horner_host(const Xyzz<F>* T, unsigned W, unsigned c, unsigned nbits, unsig
 // Fixed-base MSM (one bucket set for all digit positions): the device leaves, per pseudo-window v of `mag` magnitudes,
 // the same T[v][...] partial sums as an ordinary window; window v stands for the magnitudes v*mag + 1 .. (v+1)*mag, so
 //     result = sum_v val_v + mag * sum_v v * Stot_v        (Stot_v = T[v][nbits+1], the plain sum of the window)
+// value of one (pseudo-)window from its partial sums: 2^mlog * sum_b 2^b T[b] + T[nbits] + T[nbits + 1]
 template <class F>
-void flat_combine_host(const Xyzz<F>* T, unsigned Wr, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
+Xyzz<F> window_value_host(const Xyzz<F>* tw, unsigned nbits, unsigned mlog)
 {
+    Xyzz<F> t = Xyzz<F>::zero();
+    for (int b = (int)nbits - 1; b >= 0; b--) {
+        t = pdbl(t);
+        t = padd(t, tw[b]);
+    }
+    for (unsigned k = 0; k < mlog; k++) t = pdbl(t);
+    t = padd(t, tw[nbits]);
+    return padd(t, tw[nbits + 1]); // + sum of all X: slot i' carries the weight i' + 1
+}
+// ... of all windows, on the context's host threads when there are some: the ~30 group operations per window are the
+// longest host-side stretch on a proof's critical path (the H MSM's combine: 16 windows, ~0.25 ms serially)
+// prep(w), if given, runs first in window w's task (the conversion of that window's partial sums from the kernels' field
+// representation: it is as much work as the window's group operations)
+static thread_local const std::function<void(unsigned)>* g_window_prep = nullptr;
+template <class F>
+void window_values_host(k16_ctx* ctx, const Xyzz<F>* T, unsigned W, unsigned nbits, unsigned mlog, std::vector<Xyzz<F>>* out)
+{
+    out->resize(W);
+    k16_host_pool* pool = (W >= 4 && ctx->parallel_combine) ? k16_ctx_pool(ctx) : nullptr;
+    const std::function<void(unsigned)>* prep = g_window_prep;
+    auto one = [&](unsigned w) {
+        if (prep) (*prep)(w);
+        (*out)[w] = window_value_host<F>(T + (size_t)w * (nbits + 2), nbits, mlog);
+    };
+    if (pool)
+        pool->run(W, one);
+    else
+        for (unsigned w = 0; w < W; w++) one(w);
+}
+
+template <class F>
+void flat_combine_host(k16_ctx* ctx, const Xyzz<F>* T, unsigned Wr, unsigned c, unsigned nbits, unsigned mlog, Xyzz<F>* out)
+{
+    std::vector<Xyzz<F>> val;
+    window_values_host<F>(ctx, T, Wr, nbits, mlog, &val);
     Xyzz<F> total = Xyzz<F>::zero(), run = Xyzz<F>::zero(), wsum = Xyzz<F>::zero();
     for (int v = (int)Wr - 1; v >= 0; v--) {
         const Xyzz<F>* tw = T + (size_t)v * (nbits + 2);
-        Xyzz<F>        t  = Xyzz<F>::zero();
-        for (int b = (int)nbits - 1; b >= 0; b--) {
-            t = pdbl(t);
-            t = padd(t, tw[b]);
-        }
-        for (unsigned k = 0; k < mlog; k++) t = pdbl(t);
-        t     = padd(t, tw[nbits]);
-        t     = padd(t, tw[nbits + 1]);
-        total = padd(total, t);
+        total = padd(total, val[v]);
         if (v > 0) {                      // sum_v v * Stot_v by running sums, from the top window down
             run  = padd(run, tw[nbits + 1]);
             wsum = padd(wsum, run);
@@ -327,12 +353,18 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
         memcpy(raw.data(), src, (size_t)cnt * sizeof(Xyzz9));
         pop(); // the slot may be reused from here on
         std::vector<G1Xyzz> T(cnt);
-        for (unsigned i = 0; i < cnt; i++) T[i] = xyzz9_to_canonical(raw[i]);
+        const std::function<void(unsigned)> prep = [&](unsigned w) {
+            for (unsigned i = w * (pd.nbits + 2); i < (w + 1) * (pd.nbits + 2); i++) T[i] = xyzz9_to_canonical(raw[i]);
+        };
+        g_window_prep = &prep;
+        struct Clear {
+            ~Clear() { g_window_prep = nullptr; }
+        } clear;
         G1Xyzz r;
         if (pd.flat)
-            flat_combine_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+            flat_combine_host<Fq>(ctx, T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         else
-            horner_host<Fq>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+            horner_host<Fq>(ctx, T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G1Aff a = to_affine(r);
@@ -343,14 +375,20 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
         memcpy(raw.data(), src, (size_t)cnt * sizeof(Xyzz<Fq2n>));
         pop();
         std::vector<G2Xyzz> T(cnt);
-        for (unsigned i = 0; i < cnt; i++) {
-            const Xyzz<Fq2n>& p9 = raw[i];
-            T[i] = p9.is_zero() ? G2Xyzz::zero()
-                                : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
-                                         fq2n_to_canonical(p9.zzz)};
-        }
+        const std::function<void(unsigned)> prep = [&](unsigned w) {
+            for (unsigned i = w * (pd.nbits + 2); i < (w + 1) * (pd.nbits + 2); i++) {
+                const Xyzz<Fq2n>& p9 = raw[i];
+                T[i] = p9.is_zero() ? G2Xyzz::zero()
+                                    : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
+                                             fq2n_to_canonical(p9.zzz)};
+            }
+        };
+        g_window_prep = &prep;
+        struct Clear {
+            ~Clear() { g_window_prep = nullptr; }
+        } clear;
         G2Xyzz r;
-        horner_host<Fq2>(T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+        horner_host<Fq2>(ctx, T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G2Aff a = to_affine(r);

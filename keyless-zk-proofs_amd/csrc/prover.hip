@@ -320,29 +320,22 @@ struct k16_prover {
     struct WitnessPacker* packer = nullptr; // compact witness upload (see k_wtns_expand_*); null: plain copy
 };
 
-// Host side of the compact upload: T threads (the caller + T - 1 pooled workers) each scan a contiguous range of the witness.
+// Host side of the compact upload: the context's host threads (k16_ctx_pool) each scan a contiguous range of the witness.
 struct WitnessPacker {
-    unsigned             n_threads = 0;
-    uint32_t             n_vars    = 0;
-    uint8_t*             h_narrow  = nullptr; // pinned, device-mapped: one byte per wire
-    uint32_t*            h_idx     = nullptr; // pinned: n_threads regions of `cap` wide-value indices
-    uint8_t*             h_val     = nullptr; //         ... and their 32-byte values
-    uint8_t *            d_narrow = nullptr;
-    uint32_t*            d_idx    = nullptr;
-    uint8_t*             d_val    = nullptr;
-    uint32_t             cap      = 0; // wide values a thread's region holds (a quarter of its range: beyond that, plain copy)
+    k16_host_pool*        pool      = nullptr;
+    unsigned              n_threads = 0; // ranges (= pool width)
+    uint32_t              n_vars    = 0;
+    uint8_t*              h_narrow  = nullptr; // pinned, device-mapped: one byte per wire
+    uint32_t*             h_idx     = nullptr; // pinned: n_threads regions of `cap` wide-value indices
+    uint8_t*              h_val     = nullptr; //         ... and their 32-byte values
+    uint8_t*              d_narrow  = nullptr;
+    uint32_t*             d_idx     = nullptr;
+    uint8_t*              d_val     = nullptr;
+    uint32_t              cap       = 0; // wide values a range's region holds (a quarter of the range: beyond that, plain copy)
     std::vector<uint32_t> count;
     std::vector<uint8_t>  overflow;
-    // pool
-    std::vector<std::thread> workers;
-    std::mutex               mu;
-    std::condition_variable  cv_go, cv_done;
-    uint64_t                 gen = 0;
-    unsigned                 pending = 0;
-    bool                     quit = false;
-    const uint8_t*           src = nullptr;
 
-    void pack_range(unsigned t)
+    void pack_range(const uint8_t* src, unsigned t)
     {
         const uint64_t lo = (uint64_t)n_vars * t / n_threads, hi = (uint64_t)n_vars * (t + 1) / n_threads;
         uint32_t*      ix = h_idx + (size_t)t * cap;
@@ -368,69 +361,29 @@ struct WitnessPacker {
         count[t]    = c;
         overflow[t] = ovf;
     }
-    void worker(unsigned t)
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv_go.wait(lk, [&] { return quit || gen != seen; });
-                if (quit) return;
-                seen = gen;
-            }
-            pack_range(t);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--pending == 0) cv_done.notify_one();
-            }
-        }
-    }
     // returns false when a range had more wide values than its region holds (the caller then copies the witness plainly)
     bool pack(const void* witness)
     {
-        src = (const uint8_t*)witness;
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            pending = n_threads - 1;
-            gen++;
-        }
-        cv_go.notify_all();
-        pack_range(0);
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv_done.wait(lk, [&] { return pending == 0; });
-        }
+        const uint8_t* src = (const uint8_t*)witness;
+        pool->run(n_threads, [&](unsigned t) { pack_range(src, t); });
         for (unsigned t = 0; t < n_threads; t++)
             if (overflow[t]) return false;
         return true;
     }
     ~WitnessPacker()
     {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            quit = true;
-        }
-        cv_go.notify_all();
-        for (auto& w : workers) w.join();
         if (h_narrow) (void)hipHostFree(h_narrow);
         if (h_idx) (void)hipHostFree(h_idx);
         if (h_val) (void)hipHostFree(h_val);
     }
 };
-static unsigned packer_threads()
+static WitnessPacker* packer_create(k16_ctx* ctx, uint32_t n_vars)
 {
-    if (const char* e = getenv("K16_UPLOAD_THREADS")) return (unsigned)std::max(0, std::min(32, atoi(e)));
-    cpu_set_t set;
-    unsigned  n = 1;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
-    return std::max(1u, std::min(12u, n * 3 / 4)); // three quarters of the CPUs the process may use, at most 12
-    // (measured on a 16-CPU box, Keyless shape: plain copy p50 7.0 ms; 4 threads 6.9-7.0; 8 threads 6.5; 12 threads 6.47)
-}
-static WitnessPacker* packer_create(uint32_t n_vars)
-{
-    const unsigned T = packer_threads();
-    if (T == 0 || n_vars < (1u << 16)) return nullptr; // small circuits: the plain copy is a few microseconds
+    k16_host_pool* pool = k16_ctx_pool(ctx);
+    if (!pool || n_vars < (1u << 16)) return nullptr; // small circuits: the plain copy is a few microseconds
+    const unsigned T = std::min(pool->width(), 32u);
     WitnessPacker* w = new WitnessPacker();
+    w->pool          = pool;
     w->n_threads     = T;
     w->n_vars        = n_vars;
     w->cap           = (n_vars / T) / 4 + 64;
@@ -444,12 +397,6 @@ static WitnessPacker* packer_create(uint32_t n_vars)
         hipHostGetDevicePointer((void**)&w->d_idx, w->h_idx, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&w->d_val, w->h_val, 0) != hipSuccess) {
         (void)hipGetLastError();
-        delete w;
-        return nullptr;
-    }
-    try {
-        for (unsigned t = 1; t < T; t++) w->workers.emplace_back([w, t] { w->worker(t); });
-    } catch (...) { // no threads to be had: the plain copy still works
         delete w;
         return nullptr;
     }
@@ -670,7 +617,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // workspaces, the lane streams and the code objects of every kernel come into being here instead of inside the first
     // request (35 ms instead of 8 through the facade).  Its outcome does not decide anything: a device that cannot prove
     // says so on the first real request.  Not under fault injection, whose counter counts requests.
-    p->packer = packer_create(p->n_vars);
+    p->packer = packer_create(ctx, p->n_vars);
 #ifdef K16_TESTING
     const bool fault_env = getenv("K16_FAULT_INJECT") != nullptr;
 #else
@@ -965,7 +912,10 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     pi_b = h_madd(pi_b, p->beta2);
     pi_b = h_add(pi_b, d2_s);
     ht("B2 finished");
-    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pih, nullptr))) return rc;
+    ctx->parallel_combine = true; // the H MSM's partial sums: the one combine nothing else runs beside
+    rc                    = k16_msm_finish_group(ctx, K16_G1, &pih, nullptr);
+    ctx->parallel_combine = false;
+    if (rc) return rc;
     ht("H finished");
     K16_HIP(ctx, hipStreamWaitEvent(st, ctx->pend_ev[(ctx->pend_head + k16_ctx::PEND_SLOTS - 1) % k16_ctx::PEND_SLOTS], 0));
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
