@@ -842,3 +842,68 @@ def test_ntt_large_sizes_vs_oracle(ctx, log2n):
     a[:, 3] &= (1 << 60) - 1
     for inverse in (False, True):
         assert np.array_equal(ctx.ntt(a, max_domain=2 * n, inverse=inverse), ol.ntt(a, max_domain=2 * n, inverse=inverse))
+
+
+def test_compact_witness_upload_edge_cases(tmp_path, monkeypatch):
+    """The witness crosses PCIe in compact form for circuits of >= 2^16 wires (prover.hip WitnessPacker / k_wtns_expand_*: one
+    byte per wire + per-host-thread lists of the wide values; a list that overflows makes the proof fall back to the plain
+    copy).  What the Keyless-shape witnesses never reach: values exactly at the byte boundary and with only a high word set,
+    wide values at the first / last wire and across the host threads' range boundaries, a range holding exactly its list
+    capacity, one more than that (fallback), and a witness of nothing but wide values.  Every proof must equal the oracle's
+    (RS/groth16.cpp:41-360 reads the same 32-byte values whatever their size)."""
+    import k16
+    import zkey_builder as zb
+    monkeypatch.setenv("K16_HOST_THREADS", "4")      # four ranges: the capacities below are exact for that split
+    c = k16.Context(0)
+    try:
+        n_vars, N, n_coefs, T = 70000, 1 << 17, 200000, 4
+        zk, wt = str(tmp_path / "c.zkey"), str(tmp_path / "c.wtns")
+        zb.build_zkey(zk, n_vars, 1, N, n_coefs, seed=31)
+        p = k16.Prover(c, zk)
+        r, s = pm.limbs(pm.SplitMix64(91).below(pm.R)), pm.limbs(pm.SplitMix64(92).below(pm.R))
+        rs = np.random.RandomState(5)
+        cap = (n_vars // T) // 4 + 64
+
+        def wide(k):
+            return np.frombuffer(pm.limbs(pm.SplitMix64(1000 + k).below(pm.R)), dtype=np.uint8)
+
+        def narrow_base():
+            w = np.zeros((n_vars, 32), dtype=np.uint8)
+            w[:, 0] = rs.randint(0, 256, size=n_vars)
+            return w
+
+        cases = {}
+        w = narrow_base()
+        w[100:400, 0] = 255
+        cases["narrow_only"] = w
+        w = narrow_base()
+        edges = [1, 2, n_vars - 1] + [n_vars * t // T + d for t in range(1, T) for d in (-1, 0, 1)]
+        vals = [1 << 8, 1 << 32, 1 << 64, 1 << 128, 1 << 192, pm.R - 1, 255 + (1 << 200), (1 << 8) + 7]
+        for k, i in enumerate(edges):
+            w[i] = np.frombuffer(pm.limbs(vals[k % len(vals)]), dtype=np.uint8)
+        cases["boundary_values"] = w
+        for name, count in (("range_exactly_full", cap), ("range_overflows", cap + 1)):
+            w = narrow_base()
+            for k in range(count):
+                w[1 + k] = wide(k)
+            cases[name] = w
+        w = np.zeros((n_vars, 32), dtype=np.uint8)
+        f = rs.randint(0, 256, size=(n_vars, 32), dtype=np.uint8)
+        f[:, 31] &= 0x1F
+        f[:, 1] |= 1                                   # every value >= 256
+        cases["all_wide"] = f
+        for name, w in cases.items():
+            w[0] = 0
+            w[0, 0] = 1
+            with open(wt, "wb") as fh:
+                import struct
+                sec1 = struct.pack("<I", 32) + pm.limbs(pm.R) + struct.pack("<I", n_vars)
+                fh.write(b"wtns" + struct.pack("<II", 2, 2) + zb._section(1, sec1) + zb._section(2, w.tobytes()))
+            want, h_ref = ol.prove_files(zk, wt, r, s, nthreads=8, want_h=True)
+            got = p.prove_mem(w, r, s)
+            assert np.array_equal(p.last_h(), h_ref), name
+            assert got == want, name
+            assert p.prove_file(wt, r, s) == want, name
+        p.close()
+    finally:
+        c.close()
