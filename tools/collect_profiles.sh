@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
 python3 bench.py --steps 100 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_100steps.json 2>/dev/null
 # 2. the same command under rocprofv3 --kernel-trace --stats (kernel averages the roofline must agree with)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+K16_BENCH_NO_COLD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 # 3. PMC traffic, one counter per pass, one MSM at a time
 K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
 K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
@@ -32,12 +32,18 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/k16_tl -- python3 tools/ben
 python3 tools/proof_timeline.py /tmp/k16_tl 2 > $O/proof_timeline.txt 2>> $O/proof_timeline.err
 python3 tools/fixed_base_timing.py 21 8 > $O/fixed_base_h_msm.log 2>&1
 python3 tools/ntt_timing.py 21 30 > $O/ntt_2p21.log 2>&1
-ls -la $O
 # 10. round 3: sort lab (per-kernel averages of the product's bucket sort), verifier trace, PMC write traffic of the sort
 tools/lab/sortlab 20 16 0 uniform 20 check > $O/sortlab_2p20_c16.log 2>&1
 tools/lab/sortlab 21 20 1 uniform 20 check > $O/sortlab_2p21_flat20.log 2>&1
 tools/lab/prof.sh r03s16 tools/lab/sortlab 20 16 0 uniform 20 > $O/sortlab_2p20_c16_kernels.txt 2>&1
 tools/lab/prof.sh r03sH tools/lab/sortlab 21 20 1 uniform 20 > $O/sortlab_2p21_flat20_kernels.txt 2>&1
 tools/lab/pmc.sh r03w16 WRITE_SIZE tools/lab/sortlab 20 16 0 uniform 3 > $O/sortlab_2p20_c16_WRITE_SIZE.txt 2>&1
-K16_VERIFY_COOP_TRACE=1 python3 tools/bench_verify.py > $O/verify.json 2> $O/verify_coop_trace.log
+K16_VERIFY_COOP_TRACE=1 python3 tools/bench_verify.py > /dev/null 2> $O/verify_coop_trace.log   # (the trace build of the kernel is slower: not the numbers of record)
 ls -la $O
+# 11. summaries out of the raw rocprofv3 directories (what gets copied into profiles/r03/)
+cp "$(ls -S $(find $O/stats -name "*kernel_stats.csv") | head -1)" $O/bench_kernel_stats.csv   # (the largest: child processes write their own)
+cp "$(ls -S $(find $O/proof_stats -name "*kernel_stats.csv") | head -1)" $O/proof_keyless_shape_kernel_stats.csv
+python3 tools/pmc_kernel.py $O/pmc_fetch > $O/pmc_FETCH_SIZE_per_kernel.txt
+python3 tools/pmc_kernel.py $O/pmc_write > $O/pmc_WRITE_SIZE_per_kernel.txt
+python3 tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json > /dev/null
+rm -rf $O/stats $O/proof_stats $O/pmc_fetch $O/pmc_write

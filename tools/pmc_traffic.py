@@ -35,7 +35,7 @@ def main():
     w_kb = write.get(k, (0.0, 0))[0]
     res = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass), "
-                  "K16_BENCH_DEPTH=1 bench.py --steps 3 --warmup 1 --proofs 0; per-kernel averages in profiles/r02/pmc_*.csv",
+                  "K16_BENCH_DEPTH=1 bench.py --steps 3 --warmup 1 --proofs 0; per-kernel averages in profiles/r03/pmc_*_per_kernel.txt (tools/pmc_kernel.py on the same passes)",
         "kernel": k[:60],
         "launches_averaged": n,
         "FETCH_SIZE_KB_raw": f_kb,
@@ -50,13 +50,6 @@ def main():
                 "per non-zero digit (16 x per point) and is MALL-resident, so this is mostly MALL traffic, not HBM re-reads.",
     }
     json.dump(res, open(out, "w"), indent=1)
-    # per-kernel tables beside it
-    base = os.path.dirname(out)
-    for name, tab in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        with open(os.path.join(base, "r02", "pmc_%s_per_kernel.csv" % name), "w") as f:
-            f.write("kernel,avg_%s_KB,launches\n" % name)
-            for kk, (v, c) in sorted(tab.items(), key=lambda x: -x[1][0]):
-                f.write('"%s",%.1f,%d\n' % (kk[:100], v, c))
     print(json.dumps(res))
 
 
