@@ -912,6 +912,16 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     pi_b = h_madd(pi_b, p->beta2);
     pi_b = h_add(pi_b, d2_s);
     ht("B2 finished");
+    // pi_a and pi_b are final: their affine form and decimal strings are made while the GPU still works on the H MSM
+    const G1Aff A = to_affine(pi_a);
+    const G2Aff B = to_affine(pi_b);
+    const std::string js_ab = "{\"pi_a\":[\"" + fq_to_dec(A.x) + "\",\"" + fq_to_dec(A.y) + "\",\"1\"],\"pi_b\":[[\"" +
+                              fq_to_dec(B.x.a) + "\",\"" + fq_to_dec(B.x.b) + "\"],[\"" + fq_to_dec(B.y.a) + "\",\"" +
+                              fq_to_dec(B.y.b) + "\"],[\"1\",\"0\"]],\"pi_c\":[\"";
+    // ... and everything of pi_c but the H term (groth16.cpp:340-352; the order of the group additions does not change the point)
+    pi_c = h_add(pi_c, a_s);
+    pi_c = h_add(pi_c, b1_r);
+    pi_c = h_add(pi_c, d1_rs_neg);
     ctx->parallel_combine = true; // the H MSM's partial sums: the one combine nothing else runs beside
     rc                    = k16_msm_finish_group(ctx, K16_G1, &pih, nullptr);
     ctx->parallel_combine = false;
@@ -922,17 +932,10 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
     pi_c = h_add(pi_c, pih);
-    pi_c = h_add(pi_c, a_s);
-    pi_c = h_add(pi_c, b1_r);
-    pi_c = h_add(pi_c, d1_rs_neg);
 
-    G1Aff A = to_affine(pi_a), Cc = to_affine(pi_c);
-    G2Aff B = to_affine(pi_b);
+    const G1Aff Cc = to_affine(pi_c);
     // groth16.cpp:378-410 + dump(): keys sorted, no whitespace
-    std::string js = "{\"pi_a\":[\"" + fq_to_dec(A.x) + "\",\"" + fq_to_dec(A.y) + "\",\"1\"],\"pi_b\":[[\"" +
-                     fq_to_dec(B.x.a) + "\",\"" + fq_to_dec(B.x.b) + "\"],[\"" + fq_to_dec(B.y.a) + "\",\"" +
-                     fq_to_dec(B.y.b) + "\"],[\"1\",\"0\"]],\"pi_c\":[\"" + fq_to_dec(Cc.x) + "\",\"" +
-                     fq_to_dec(Cc.y) + "\",\"1\"],\"protocol\":\"groth16\"}";
+    std::string js = js_ab + fq_to_dec(Cc.x) + "\",\"" + fq_to_dec(Cc.y) + "\",\"1\"],\"protocol\":\"groth16\"}";
     if (js.size() + 1 > cap) return K16_ERR_BUFFER;
     memcpy(out_json, js.c_str(), js.size() + 1);
     return (int)js.size();
