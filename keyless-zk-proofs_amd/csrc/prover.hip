@@ -933,11 +933,13 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
     pi_c = h_add(pi_c, pih);
 
+    ht("device joined");
     const G1Aff Cc = to_affine(pi_c);
     // groth16.cpp:378-410 + dump(): keys sorted, no whitespace
     std::string js = js_ab + fq_to_dec(Cc.x) + "\",\"" + fq_to_dec(Cc.y) + "\",\"1\"],\"protocol\":\"groth16\"}";
     if (js.size() + 1 > cap) return K16_ERR_BUFFER;
     memcpy(out_json, js.c_str(), js.size() + 1);
+    ht("proof JSON written");
     return (int)js.size();
 }
 
