@@ -58,7 +58,11 @@ enum { K16_FQ9 = 2, K16_FR9 = 3, K16_FQ2N = 4 };
 enum { K16_G1_ENG9 = 2, K16_G2_ENG2N = 3 };
 #define K16_OP_BOUND_A(k) ((k) << 8)
 #define K16_OP_BOUND_B(k) ((k) << 12)
-enum { K16_OP_ADD = 0, K16_OP_SUB, K16_OP_NEG, K16_OP_MUL, K16_OP_SQR, K16_OP_TOMONT, K16_OP_FROMMONT };
+enum { K16_OP_ADD = 0, K16_OP_SUB, K16_OP_NEG, K16_OP_MUL, K16_OP_SQR, K16_OP_TOMONT, K16_OP_FROMMONT,
+       /* K16_FQ9 / K16_FR9 only: the NTT butterflies' lazy-limb forms (bn254_fq9.h fadd9_lazy, fsub9_lazy4_t) followed by the
+        * multiplication that consumes them: (a + b) * b and (a - b) * b; K16_OP_BOUND_A counts in steps of 2 moduli here
+        * (up to a + 30 p), b stays below 2 p as in the kernels */
+       K16_OP_LAZY_ADDMUL, K16_OP_LAZY_SUBMUL };
 enum { K16_PT_ADD = 0, K16_PT_MADD, K16_PT_DBL };
 
 typedef struct k16_ctx    k16_ctx;

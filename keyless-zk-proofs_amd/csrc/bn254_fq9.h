@@ -237,6 +237,33 @@ K16_HD Fq9 fsub9(const Fq9& a, const Fq9& b)
     return fsub9_t<Fq9C, K>(a, b);
 }
 
+// ---- the same without carry propagation ("lazy" limbs), for values that go straight into ONE normalising operation or
+// into a multiplication as its only lazy operand (NTT butterflies, ntt.hip).
+// a + b limb by limb: limbs < 2^30 for normalised inputs.  A multiplication takes such an operand against a normalised one:
+// a column is at most 9 * 2^30 * 2^29 + 9 * 2^58 + carry < 2^64.
+K16_HD Fq9 fadd9_lazy(const Fq9& a, const Fq9& b)
+{
+    Fq9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+// a - b + 4p limb by limb.  4p is written with 2^29 lent to each of the limbs 0..7 by the limb above (l'[0] = l[0] + 2^29,
+// l'[i] = l[i] + 2^29 - 1, l'[8] = l[8] - 1), so that no limb of the result is negative: needs b NORMALISED and b < 2p
+// (top limb of b <= top limb of 2p < l[8](4p) - 1); a normalised.  Result limbs < 3 * 2^29 (a multiplication column against
+// a normalised operand: 27 * 2^58 + 9 * 2^58 + carry < 2^64), value < A + 4.
+template <class C>
+K16_HD Fq9 fsub9_lazy4_t(const Fq9& a, const Fq9& b)
+{
+    Fq9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t kp = i == 0 ? C::KP4[0] + (1u << 29) : (i < 8 ? C::KP4[i] + (1u << 29) - 1u : C::KP4[8] - 1u);
+        r.l[i]            = a.l[i] + kp - b.l[i];
+    }
+    return r;
+}
+
 // exact comparison with j*p, j = 0 .. J-1, for a normalised value < J*p:  V == 0 (mod p) ?
 // Prefilter on the low limb (false positives ~ J / 2^29), then a full 9-limb compare.
 template <int J>
@@ -467,7 +494,7 @@ K16_HD Xyzz9 xyzz9_from_canonical(const Xyzz<Fq>& p)
 // ------------------------------------------------------------------------------------------------
 // v < 32p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17)):
 // v / 2^232 < (q + 1) * 3171407 and p / 2^232 > 3171406.3, so the remainder is below p (1 + (q + 1) * 2.2e-7) -- 7.1e-6 at
-// q = 31, against 2^-17 = 7.6e-6 (the NTT passes reduce tile values of up to 26 r with it); the reciprocal estimate is exact
+// q = 31, against 2^-17 = 7.6e-6 (the NTT passes reduce tile values of up to 32 r with it); the reciprocal estimate is exact
 // or one less for top limbs below 2^27 (error t * 0.2 / 2^44 << 1), which the correction step settles.
 template <class C>
 K16_HD Fq9 fred9_t(const Fq9& v)

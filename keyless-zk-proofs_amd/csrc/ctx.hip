@@ -429,6 +429,8 @@ __global__ void k_field_op9(int op, unsigned ka, unsigned kb, const Fp<PR>* __re
     case K16_OP_NEG: z = f9_out<C, PR>(fsub9_t<C, 8>(fq9_zero(), x)); break;
     case K16_OP_MUL: z = f9_out<C, PR>(fmul9_t<C>(x, y)); break;                  // needs (2+ka)(2+kb) <= 128
     case K16_OP_SQR: z = f9_out<C, PR>(fsqr9_t<C>(x)); break;
+    case K16_OP_LAZY_ADDMUL: z = f9_out<C, PR>(fmul9_t<C>(y, fadd9_lazy(add_kp<C>(x, ka), y))); break;      // ka counted twice: x + 2 ka p
+    case K16_OP_LAZY_SUBMUL: z = f9_out<C, PR>(fmul9_t<C>(y, fsub9_lazy4_t<C>(add_kp<C>(x, ka), y))); break; // (2 + 2 ka + 4) * 2 <= 128
     case K16_OP_TOMONT: { // x*R: ((x/R)*R') * R^2 / R'
         Fp<PR> r2 = Fp<PR>::r2();
         Fq9    v  = fmul9_t<C>(x, fq9_unpack(r2.v));
@@ -606,7 +608,10 @@ extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, 
     if (!c || !h_a || !h_r || field < K16_FQ || field > K16_FQ2N) return K16_ERR_ARG;
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
-    if ((ka || kb) && (field < K16_FQ9 || field == K16_FQ2N || ka > 6 || kb > 6)) return K16_ERR_ARG;
+    const bool lazy = op == K16_OP_LAZY_ADDMUL || op == K16_OP_LAZY_SUBMUL;
+    if (lazy && (field != K16_FQ9 && field != K16_FR9 || kb || ka > 14 || !h_b)) return K16_ERR_ARG;
+    if (!lazy && (ka || kb) && (field < K16_FQ9 || field == K16_FQ2N || ka > 6 || kb > 6)) return K16_ERR_ARG;
+    if (!lazy && op > K16_OP_FROMMONT) return K16_ERR_ARG;
     if (field == K16_FQ2N && op > K16_OP_SQR) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(c, hipSetDevice(c->device));

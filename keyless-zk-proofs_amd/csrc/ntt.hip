@@ -146,10 +146,11 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    // Lazy reduction inside the pass: tile values enter < 2r and grow by 2r per stage (u + t, u - t + 2r with t < 2r
-    // fresh from the multiply; the twiddle-free first two stages of a transform end < 8r), so after K <= 11 stages they
-    // are < 26r < 2^259 -- within the 9 x 29-bit limbs and within
-    // the multiply's operand bound (2 * 26 <= 128); one fred9 at the store brings them back.
+    // Lazy reduction inside the pass: tile values enter < 2r and grow by at most 6r per double stage (stage t: u + t < +2r,
+    // u - t + 4r; stage t+1: + 2r again, with every t < 2r fresh from a multiplication; the twiddle-free first two stages of a
+    // transform end < 8r; an odd leading single stage adds 2r), so after K <= 10 stages (ntt_passes) they are < 32r < 2^259 --
+    // within the 9 x 29-bit limbs, within the multiply's operand bound (2 * 32 <= 128) and within fred9's range; one fred9
+    // at the store brings them back.
     const uint32_t nbf = telem >> 1;
     uint32_t       t   = 1;
     if (K & 1) { // odd stage count: one plain radix-2 stage first
@@ -193,8 +194,21 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
                 p1     = frmul9(w1, x1);
                 p3     = frmul9(w1, x3);
             }
-            Fr9 a0 = fadd9(x0, p1), a1 = fsub9_t<Fr9C, 2>(x0, p1);
-            Fr9 a2 = fadd9(x2, p3), a3 = fsub9_t<Fr9C, 2>(x2, p3);
+            // Stage t's sums and differences are consumed once each -- a2 / a3 by a multiplication, a0 / a1 by a normalising
+            // addition / subtraction -- so (outside the twiddle-free opening stages) they keep lazy limbs: 54 instead of 122
+            // instructions for the four of them.  The differences then carry +4r instead of +2r (see fsub9_lazy4_t).
+            Fr9 a0, a1, a2, a3;
+            if (unit) {
+                a0 = fadd9(x0, p1);
+                a1 = fsub9_t<Fr9C, 2>(x0, p1);
+                a2 = fadd9(x2, p3);
+                a3 = fsub9_t<Fr9C, 2>(x2, p3);
+            } else {
+                a0 = fadd9_lazy(x0, p1);
+                a1 = fsub9_lazy4_t<Fr9C>(x0, p1);
+                a2 = fadd9_lazy(x2, p3);
+                a3 = fsub9_lazy4_t<Fr9C>(x2, p3);
+            }
             Fr9 q2 = unit ? a2 : frmul9(ld_r9(&roots9[ja << (S - s0 - t - 1)]), a2);
             Fr9 q3 = frmul9(ld_r9(&roots9[jb << (S - s0 - t - 1)]), a3);
             tile[i0]          = fadd9(a0, q2);
@@ -216,7 +230,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
             const uint32_t f   = (uint32_t)base + (mid << s0) + tl;
             const uint32_t i   = (0u - f) & nm1;                       // (n - f) mod n
             const uint32_t to  = logn ? (__brev(i) >> (32 - logn)) : 0u;
-            st_r9(&d[to], frmul9(tile[mid * RS + tl], ld_r9(&shift9[i]))); // 26 * 2 <= 128: < 2r
+            st_r9(&d[to], frmul9(tile[mid * RS + tl], ld_r9(&shift9[i]))); // 32 * 2 <= 128: < 2r
         }
         return;
     }

@@ -17,7 +17,7 @@ OPT_GRAPHS = 2
 FQ, FR = 0, 1
 FQ9, FR9, FQ2N = 2, 3, 4          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
 G1_ENG9, G2_ENG2N = 2, 3
-OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT = range(7)
+OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT, OP_LAZY_ADDMUL, OP_LAZY_SUBMUL = range(9)
 PT_ADD, PT_MADD, PT_DBL = range(3)
 AFF_BYTES = {G1: 64, G2: 128, G1_ENG9: 64, G2_ENG2N: 128}
 XYZZ_BYTES = {G1: 128, G2: 256, G1_ENG9: 128, G2_ENG2N: 256}

@@ -95,6 +95,40 @@ int main()
         CHECK(fq9_is_zero_mod_p<10>(fsub9<8>(A, A)), "x - x == 0 mod p");
         CHECK(fq9_is_zero_mod_p<4>(A) == a.is_zero(), "is_zero");
     }
+    // lazy-limb forms of the NTT butterflies (ntt.hip): fadd9_lazy / fsub9_lazy4_t feeding a multiplication or a normalising
+    // addition / subtraction, with the left operand up to 30p and worst-case limb patterns (all limbs 2^29 - 1 / 0)
+    for (int it = 0; it < 20000; it++) {
+        Fq a = rand_fq(), b = rand_fq(), w = rand_fq();
+        Fq9 A = fq9_from_fq(a), B = fq9_from_fq(b), W = fq9_from_fq(w);
+        Fq  big = a;
+        Fq9 BIG = A;
+        const int extra = it % 15; // BIG = A + 2 * extra * p  (same field element)
+        {
+            Fq9 pp;
+            for (int i = 0; i < 9; i++) pp.l[i] = Fq9C::P[i];
+            for (int j = 0; j < 2 * extra; j++) BIG = fadd9(BIG, pp);
+        }
+        if (it % 7 == 3) { // B with every low limb at its maximum (still < 2p: top limb 0x30644e < top limb of 2p)
+            for (int i = 0; i < 8; i++) B.l[i] = Fq9C::MASK;
+            B.l[8] = 0x30644e;
+            b      = fq9_to_fq(B);
+        }
+        if (it % 7 == 5) { // BIG with all-zero low limbs (the difference then lives on the lent 2^29s alone)
+            for (int i = 0; i < 8; i++) BIG.l[i] = 0;
+            big = fq9_to_fq(BIG);
+        }
+        Fq9 s = fadd9_lazy(BIG, B), d = fsub9_lazy4_t<Fq9C>(BIG, B);
+        bool limbs_ok = true;
+        for (int i = 0; i < 9; i++) limbs_ok = limbs_ok && s.l[i] < (1u << 30) + (1u << 27) && d.l[i] < 3u * (1u << 29);
+        CHECK(limbs_ok, "lazy limb bounds");
+        CHECK(fq9_to_fq(fmul9(W, s)) == fmul(w, fadd(big, b)), "w * (a + b), lazy sum");
+        CHECK(fq9_to_fq(fmul9(W, d)) == fmul(w, fsub(big, b)), "w * (a - b), lazy difference");
+        Fq9 q = fmul9(W, A); // a fresh product (< 2p), the other operand of the second butterfly stage
+        CHECK(normalised(fadd9(s, q)) && fq9_to_fq(fmul9(W, fadd9(s, q))) == fmul(w, fadd(fadd(big, b), fmul(w, a))), "lazy sum + product");
+        CHECK(normalised(fadd9(d, q)) && fq9_to_fq(fmul9(W, fadd9(d, q))) == fmul(w, fadd(fsub(big, b), fmul(w, a))), "lazy difference + product");
+        CHECK(normalised(fsub9<2>(s, q)) && fq9_to_fq(fmul9(W, fsub9<2>(s, q))) == fmul(w, fsub(fadd(big, b), fmul(w, a))), "lazy sum - product");
+        CHECK(normalised(fsub9<2>(d, q)) && fq9_to_fq(fmul9(W, fsub9<2>(d, q))) == fmul(w, fsub(fsub(big, b), fmul(w, a))), "lazy difference - product");
+    }
     // curve ops: random walks mixing madd / add / dbl with the exceptional cases
     G1Aff g;
     g.x = Fq::one();

@@ -907,3 +907,28 @@ def test_compact_witness_upload_edge_cases(tmp_path, monkeypatch):
         p.close()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("field,sel", [(0, "FQ9"), (1, "FR9")])
+def test_lazy_limb_butterfly_forms(ctx, field, sel):
+    """fadd9_lazy / fsub9_lazy4_t (bn254_fq9.h): the NTT double stage keeps the sums and differences of its first stage
+    without carry propagation and feeds them straight into the next multiplication (ntt.hip).  (a + b) * b and
+    (a - b) * b with a moved up to a + 28 p (the passes reach 32 r) against the oracle's canonical arithmetic."""
+    import k16
+    p = pm.Q if field == 0 else pm.R
+    rng = pm.SplitMix64(4242 + field)
+    n = 8192
+    a, b = rand_fe_array(rng, p, n), rand_fe_array(rng, p, n)
+    edge = [0, 1, p - 1, p - 2, (1 << 29) - 1, 1 << 29, (1 << 232) - 1, 1 << 232, (p >> 1), (p >> 1) + 1]
+    for i, v in enumerate(edge):          # raw stored values (Montgomery form is just another field element here)
+        a[i] = np.frombuffer(pm.limbs(v), dtype=np.uint64)
+        b[len(edge) + i] = np.frombuffer(pm.limbs(v), dtype=np.uint64)
+        a[2 * len(edge) + i] = b[2 * len(edge) + i] = np.frombuffer(pm.limbs(v), dtype=np.uint64)
+    selv = getattr(k16, sel)
+    add = ol.field_op_vec(field, k16.OP_ADD, a, b)
+    sub = ol.field_op_vec(field, k16.OP_SUB, a, b)
+    want_add = ol.field_op_vec(field, k16.OP_MUL, add, b)
+    want_sub = ol.field_op_vec(field, k16.OP_MUL, sub, b)
+    for ka in (0, 1, 7, 13, 14):
+        assert np.array_equal(ctx.field_op_vec(selv, k16.op_bound(k16.OP_LAZY_ADDMUL, ka), a, b), want_add), (sel, ka)
+        assert np.array_equal(ctx.field_op_vec(selv, k16.op_bound(k16.OP_LAZY_SUBMUL, ka), a, b), want_sub), (sel, ka)
