@@ -97,7 +97,7 @@ struct k16_kstat {
 struct k16_ntt_table {
     uint32_t  s      = 0; // log2 size
     k16::Fr*  roots  = nullptr; // device, 2^s entries, canonical Montgomery (R = 2^256)
-    k16::Fr*  roots9 = nullptr; // device, the same roots as packed R' values (x * 2^261 mod r), see bn254_fq9.h
+    uint32_t* roots9 = nullptr; // device, the same roots as R' values (x * 2^261 mod r, < 2r) in nine 29-bit limbs each (36 bytes), see ntt.hip
     k16::Fr   pow2inv[34];
     k16::Fq9  pow2inv9[34];     // 2^-k as Fr9
 };

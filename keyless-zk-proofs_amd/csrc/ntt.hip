@@ -112,6 +112,16 @@ __device__ __forceinline__ void st_r9(Fr* p, const Fr9& v)
     fr9_store(w.v, v);
     st_fr(p, w);
 }
+// Twiddles are stored UNPACKED, nine 29-bit limbs (36 bytes) per root: a double stage loads three of them, and unpacking a
+// 32-byte value costs 17 instructions each time (round 3; the data in HBM stays packed: it is loaded once per pass).
+__device__ __forceinline__ Fr9 ld_tw9(const uint32_t* __restrict__ tw, size_t i)
+{
+    Fr9             r;
+    const uint32_t* p = tw + i * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = p[k];
+    return r;
+}
 // Up to three polynomials per launch (blockIdx.y): the prover's a / b / c chains are independent, and a pass of one
 // polynomial spends a quarter of its time filling and draining the chip (all resident workgroups load before any computes).
 struct NttPtrs {
@@ -125,7 +135,7 @@ struct NttPtrs {
 // The tile is read mid-major for that store (the mid bits are the LOW bits of bitrev(i): runs of 2^K * 32 bytes in dst),
 // with one element of padding per tile row so that the LDS reads stay conflict-free.
 template <bool CONV_IN, bool CONV_OUT, bool TAIL>
-__global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restrict__ roots9, uint32_t s0, uint32_t K,
+__global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const uint32_t* __restrict__ roots9, uint32_t s0, uint32_t K,
                                                    uint32_t TL, uint32_t S, uint32_t logn, const Fr* __restrict__ shift9)
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
@@ -162,7 +172,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
             const size_t   j  = ((size_t)ml << s0) + lo0 + tl;
             Fr9            x1 = tile[m1 * RS + tl];
             Fr9            u  = tile[m0 * RS + tl];
-            Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_r9(&roots9[j << (S - s0 - t)]), x1); // s0 == 0: the twiddle is 1
+            Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_tw9(roots9, j << (S - s0 - t)), x1); // s0 == 0: the twiddle is 1
             tile[m0 * RS + tl] = fadd9(u, tt);
             tile[m1 * RS + tl] = fsub9_t<Fr9C, 2>(u, tt);
         }
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
                 p1 = x1;
                 p3 = x3;
             } else {
-                Fr9 w1 = ld_r9(&roots9[ja << (S - s0 - t)]);
+                Fr9 w1 = ld_tw9(roots9, ja << (S - s0 - t));
                 p1     = frmul9(w1, x1);
                 p3     = frmul9(w1, x3);
             }
@@ -209,8 +219,8 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
                 a2 = fadd9_lazy(x2, p3);
                 a3 = fsub9_lazy4_t<Fr9C>(x2, p3);
             }
-            Fr9 q2 = unit ? a2 : frmul9(ld_r9(&roots9[ja << (S - s0 - t - 1)]), a2);
-            Fr9 q3 = frmul9(ld_r9(&roots9[jb << (S - s0 - t - 1)]), a3);
+            Fr9 q2 = unit ? a2 : frmul9(ld_tw9(roots9, ja << (S - s0 - t - 1)), a2);
+            Fr9 q3 = frmul9(ld_tw9(roots9, jb << (S - s0 - t - 1)), a3);
             tile[i0]          = fadd9(a0, q2);
             // unit: q2 = a2 = x2 + x3 is not fresh from a multiplication -- up to 4r, so the offset must be 4r (with 2r the
             // difference goes negative when x2, x3 >= r and x0 + x1 is small: about once per 10^3 proofs of 2^21 with
@@ -244,11 +254,11 @@ __global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const Fr* __restr
     }
 }
 // shift9[i] = 2^-logn * g^i, g the primitive 2^(logn+1)-th root: the factor between the inverse and the coset-forward transform
-__global__ void __launch_bounds__(256) k_build_shift9(Fr* __restrict__ shift9, const Fr* __restrict__ roots9, uint32_t n,
+__global__ void __launch_bounds__(256) k_build_shift9(Fr* __restrict__ shift9, const uint32_t* __restrict__ roots9, uint32_t n,
                                                       uint32_t stride_log, Fr9 scale)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st_r9(&shift9[i], fred9_t<Fr9C>(frmul9(ld_r9(&roots9[(size_t)i << stride_log]), scale)));
+    if (i < n) st_r9(&shift9[i], fred9_t<Fr9C>(frmul9(ld_tw9(roots9, (size_t)i << stride_log), scale)));
 }
 // fft.cpp:226-245 on packed R' data
 __global__ void __launch_bounds__(256) k_inv_tail9(Fr* __restrict__ a, uint32_t logn, Fr9 scale)
@@ -265,10 +275,13 @@ __global__ void __launch_bounds__(256) k_inv_tail9(Fr* __restrict__ a, uint32_t 
     st_r9(&a[i], frmul9(y, scale));
     st_r9(&a[n - i], frmul9(x, scale));
 }
-__global__ void __launch_bounds__(256) k_roots_to_r9(const Fr* __restrict__ roots, Fr* __restrict__ roots9, uint64_t n)
+__global__ void __launch_bounds__(256) k_roots_to_r9(const Fr* __restrict__ roots, uint32_t* __restrict__ roots9, uint64_t n)
 {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st_r9(&roots9[i], fr9_from_fr(ld_fr(&roots[i])));
+    if (i >= n) return;
+    const Fr9 v = fr9_from_fr(ld_fr(&roots[i])); // < 2r, normalised
+#pragma unroll
+    for (int k = 0; k < 9; k++) roots9[i * 9 + k] = v.l[k];
 }
 
 uint32_t ilog2_u64(uint64_t n)
@@ -327,7 +340,7 @@ int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out)
     uint64_t nr = 1ull << s;
     hipLaunchKernelGGL(k_build_roots, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, t.roots, s, pt);
     K16_HIP(ctx, hipGetLastError());
-    K16_HIP(ctx, hipMalloc((void**)&t.roots9, sizeof(Fr) << s));
+    K16_HIP(ctx, hipMalloc((void**)&t.roots9, (size_t)36 << s));
     hipLaunchKernelGGL(k_roots_to_r9, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, t.roots, t.roots9, nr);
     K16_HIP(ctx, hipGetLastError());
     for (int k = 0; k <= 33; k++) t.pow2inv9[k] = fr9_from_fr(t.pow2inv[k]);
