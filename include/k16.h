@@ -149,6 +149,31 @@ int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_prepared, co
 int k16_msm_fixed_base_info(uint64_t n, unsigned* c, uint64_t* table_rows);
 int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_table);
 int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d_table, const void* d_scalars, uint64_t n);
+/* Scalar-class MSM: for scalar vectors that are mostly small -- the wire values of a circom witness: zeros, ones, bytes, a
+ * few field elements.  Replaces what the zero-digit skip of the reference's bucket loop (multiexp.cpp:59-65, `if
+ * (chunkValue)`) does for its four witness MSMs (groth16.cpp:88-112).  One classification of the scalars serves every
+ * table indexed by the same wires:
+ *     sum_i s_i P_i  =  sum_{b<8} 2^b (sum of the P_i with s_i < 256 and bit b of s_i set)  +  MSM over the s_i >= 256
+ * k16_msm_zero_row_mask:     bit i of d_mask ((n + 63) / 64 x 8 bytes) = row i of the table is (0,0); such rows are left out
+ *                            of that table's lists (they add nothing: curve.cpp:185-250).  Works on zkey-format and prepared
+ *                            tables alike ((0,0) stays (0,0)).
+ * k16_scalar_classes_create: workspace for up to max_n scalars and max_sets (1..4) tables with different zero rows.
+ * k16_scalar_classes_build:  classifies d_scalars[0..n) on the current lane's stream; d_zero_masks[s] (may be NULL) is the
+ *                            mask of set s.  n_wide_bound < 0: waits and reads the number of scalars >= 256 back; >= 0: the
+ *                            caller's upper bound on it (nothing waits; a larger actual count makes k16_msm_finish of every
+ *                            MSM enqueued from these classes fail with K16_ERR_ARG instead of returning a wrong sum).
+ * k16_msm_enqueue_classified: the MSM of one PREPARED table (k16_msm_bases_prepare) with the classified scalars, on the
+ *                            current lane; result through k16_msm_finish*, same value as k16_msm_enqueue_prepared with the
+ *                            original scalars.  The classes must not be rebuilt while such an MSM is in flight.
+ * k16_scalar_classes_counts: list lengths of the last build, out[s * 8 + b], then the wide count (tests). */
+typedef struct k16_scalar_classes k16_scalar_classes;
+int  k16_msm_zero_row_mask(k16_ctx* ctx, int group, const void* d_rows, uint64_t n, void* d_mask);
+int  k16_scalar_classes_create(k16_ctx* ctx, uint64_t max_n, int max_sets, k16_scalar_classes** out);
+void k16_scalar_classes_destroy(k16_scalar_classes* cls);
+int  k16_scalar_classes_build(k16_ctx* ctx, k16_scalar_classes* cls, const void* d_scalars, uint64_t n,
+                              const void* const* d_zero_masks, int n_sets, int64_t n_wide_bound);
+int  k16_scalar_classes_counts(k16_ctx* ctx, const k16_scalar_classes* cls, uint32_t* out);
+int  k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set);
 /* A context has K16_MSM_LANES independent MSM lanes (HIP stream + workspace).  The next k16_msm_enqueue* uses the
  * selected lane; MSMs on different lanes may overlap on the GPU (their inputs must already be complete: uploads
  * through k16_h2d are).  k16_msm_finish still returns results in enqueue order.  Default lane 0. */

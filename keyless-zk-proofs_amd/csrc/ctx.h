@@ -123,7 +123,7 @@ struct k16_ctx {
     struct Lane {
         hipStream_t stream = nullptr;
         k16_devbuf  ws_counts, ws_offsets, ws_cursor, ws_sorted, ws_segoff, ws_segbucket, ws_partial, ws_big, ws_misc,
-            ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv;
+            ws_lvl_a, ws_lvl_b, ws_lvl_c, ws_lvl_d, ws_scan, ws_conv, ws_narrow;
         // bucket sort still valid in this lane's workspace (same scalars, n, c): see reuse_sort
         // hipGraph replay of the launch-bound parts of an MSM (see graphs_on): key -> state / executable graph
         struct GraphEntry {
@@ -161,7 +161,12 @@ struct k16_ctx {
         bool     flat = false; // fixed-base MSM: w = pseudo-windows of the single bucket set
         uint64_t n = 0;
         int      slot = 0;
+        // scalar-class MSM (k16_msm_enqueue_classified): the staging slot also holds `narrow` masked point sums S_b (the wires
+        // below 2^narrow with bit b set) at NARROW_OFF; the result is the windows' value + sum_b 2^b S_b
+        unsigned narrow = 0;
+        const struct k16_scalar_classes* cls = nullptr;
     };
+    static constexpr size_t NARROW_OFF = SLOT_BYTES - 4096; // 8 points of <= 288 bytes at the end of a staging slot
     // One thread may enqueue while another finishes (bench.py does: launches on a slow host then overlap the wait for the
     // GPU): the ring bookkeeping and the host timers are guarded; everything else an enqueue touches is its own.
     std::mutex ring_mu;
@@ -187,6 +192,9 @@ struct k16_ctx {
     // lane whose sort the next MSM reuses (-1: the MSM's own lane).  With another lane the MSM reads that lane's index
     // lists but runs on its own stream with its own partial / reduction buffers, i.e. concurrently with that lane's MSMs.
     int         reuse_sort_lane = -1;
+    // table-row indirection of the NEXT bucket sort (consumed by it): the sort's scalars are a compacted subset, point k of
+    // it is row remap_next[k] of the tables (k16_msm_enqueue_classified: the wide scalars of a witness)
+    const uint32_t* remap_next = nullptr;
     // K16_SERIALIZE_ACC=1 (bench.py sets it): a lane's bucket accumulation waits for the previous lane's.  Two of these
     // chip-filling kernels never overlap anyway (kernel traces: the second starts when the first ends), so nothing is
     // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence
@@ -223,6 +231,25 @@ struct k16_ctx {
     // the last item on a proof's critical path; for MSMs whose combine overlaps GPU work, waking the pool only costs)
     bool                              parallel_combine = false;
 };
+// Scalar classes of one scalar vector (msm_classes.hip; include/k16.h k16_scalar_classes_*): per mask set and bit b < 8 the
+// list of wires whose scalar is below 256, has bit b set and whose table row is not (0,0); the scalars of 256 and above
+// ("wide") compacted into an array of their own with their wire numbers.
+struct k16_scalar_classes {
+    static constexpr int MAX_SETS = 4, BITS = 8;
+    k16_ctx*   ctx      = nullptr;
+    uint64_t   cap_n    = 0;        // scalars it can classify
+    int        max_sets = 0, n_sets = 0;
+    uint64_t   n        = 0;        // scalars of the last build
+    uint64_t   n_wide   = 0;        // rows of d_wide_scalars the wide MSM runs over (exact count, or the caller's bound)
+    uint32_t*  d_cnt    = nullptr;  // [MAX_SETS * BITS] list lengths | [32] wide count
+    uint32_t*  d_lists  = nullptr;  // [max_sets * BITS][cap_n] wire numbers
+    uint32_t*  d_wide_idx     = nullptr; // [cap_n]
+    uint8_t*   d_wide_scalars = nullptr; // [cap_n * 32]
+    uint32_t*  h_flags  = nullptr;  // pinned, device-mapped: [0] more wide scalars than announced, [1 ..] copy of d_cnt (sync build)
+    uint32_t*  h_flags_dev = nullptr;
+    hipEvent_t built    = nullptr;  // recorded behind the classification
+};
+
 // the context's host thread pool, or nullptr (K16_HOST_THREADS=1, or no thread could be started): callers then loop serially
 k16_host_pool* k16_ctx_pool(k16_ctx* ctx);
 

@@ -114,7 +114,7 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     for (auto& L : c->lanes) {
         k16_devbuf* bufs[] = {&L.ws_counts, &L.ws_offsets, &L.ws_cursor, &L.ws_sorted, &L.ws_segoff, &L.ws_segbucket,
                               &L.ws_partial, &L.ws_big, &L.ws_misc, &L.ws_lvl_a, &L.ws_lvl_b, &L.ws_lvl_c,
-                              &L.ws_lvl_d, &L.ws_scan, &L.ws_conv};
+                              &L.ws_lvl_d, &L.ws_scan, &L.ws_conv, &L.ws_narrow};
         for (auto* b : bufs)
             if (b->p) (void)hipFree(b->p);
     }

@@ -17,6 +17,8 @@ int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_ou
 int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out, hipStream_t st);
 int k16_msm_fixed_tables_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, unsigned c, unsigned W, void* d_table);
 int k16_msm_enqueue_fixed_g1(k16_ctx* ctx, const void* d_table, const void* d_scalars, uint64_t n, unsigned c);
+int k16_msm_enqueue_classified_g1(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c, bool* has_wide);
+int k16_msm_enqueue_classified_g2(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c, bool* has_wide);
 
 namespace {
 constexpr unsigned MAX_C = 16;
@@ -287,6 +289,63 @@ extern "C" int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_p
     return msm_enqueue_any(ctx, group, d_prepared, d_scalars, n, 1);
     });
 }
+// Scalar-class MSM of one prepared table (msm_kernels.inc "Scalar-class MSM", msm_classes.hip): masked sums of the wires
+// below 256 + the ordinary MSM over the compacted wide scalars; results through k16_msm_finish like any other MSM.
+extern "C" int k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set)
+{
+    return k16_guard(ctx, [&]() -> int {
+    if (!ctx || !cls || cls->ctx != ctx || (group != K16_G1 && group != K16_G2) || set < 0 || set >= cls->n_sets ||
+        (cls->n && !d_prepared))
+        return K16_ERR_ARG;
+    HostTimer ht(ctx, "host_enqueue");
+    K16_HIP(ctx, hipSetDevice(ctx->device));
+    int idx;
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
+            ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
+            return K16_ERR_ARG;
+        }
+        idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
+    }
+    k16_ctx::Pend pd;
+    pd.group = group;
+    pd.n     = cls->n;
+    pd.slot  = idx;
+    if (cls->n != 0) {
+        // window size of the wide part (a Keyless witness has ~27 k wide values): log2(n) - 1, i.e. 13 there -- few entries
+        // per bucket, so a lane's chain of additions is short (these MSMs are latency-bound beside the polynomial chain)
+        // and no bucket spans segments; c = 11 would be 10 % less work and twice the chain
+        unsigned c = ctx->forced_c;
+        if (c < MIN_C || c > MAX_C) {
+            unsigned lg = 0;
+            while ((std::max<uint64_t>(cls->n_wide, 1) >> (lg + 1)) != 0) lg++;
+            c = (unsigned)std::min<int>(MAX_C, std::max<int>(MIN_C, (int)lg - 1));
+        }
+        ctx->enq_slot    = idx;
+        bool has_wide    = false;
+        int  rc = group == K16_G1 ? k16_msm_enqueue_classified_g1(ctx, d_prepared, cls, set, c, &has_wide)
+                                  : k16_msm_enqueue_classified_g2(ctx, d_prepared, cls, set, c, &has_wide);
+        if (rc) return rc;
+        pd.cls    = cls;
+        pd.narrow = k16_scalar_classes::BITS;
+        if (has_wide) {
+            pd.c     = c;
+            pd.w     = n_windows(c);
+            pd.nbits = ctx->pend_nbits;
+            pd.mlog  = ctx->pend_mlog;
+        }
+        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], k16_lane_stream(ctx, ctx->cur_lane)));
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->ring_mu);
+        ctx->pend[idx] = pd;
+        ctx->pend_count++;
+    }
+    return K16_OK;
+    });
+}
+
 extern "C" int k16_msm_bases_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_out)
 {
     return k16_guard(ctx, [&]() -> int {
@@ -346,11 +405,24 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
     HostTimer hc(ctx, "host_finish_combine");
     const char*    src = (const char*)ctx->pinned + (size_t)pd.slot * k16_ctx::SLOT_BYTES;
     const unsigned cnt = pd.w * (pd.nbits + 2);
+    if (pd.cls && pd.cls->h_flags[0]) { // the classification met more wide scalars than its caller announced: some were dropped
+        pop();
+        ctx->err = "k16_msm_finish: the scalar classes were built with a wide-scalar bound below the actual count";
+        return K16_ERR_ARG;
+    }
+    // scalar-class MSM: + sum_b 2^b S_b over the masked sums staged behind the window sums (Horner from the top bit)
+    auto add_narrow = [&](auto& r, const auto& S) {
+        auto acc = S[pd.narrow - 1];
+        for (int b = (int)pd.narrow - 2; b >= 0; b--) acc = padd(pdbl(acc), S[b]);
+        r = padd(r, acc);
+    };
     if (group == K16_G1) {
         // the G1 kernels work in the radix-2^29 / R' domain: bring the few window/bit sums back to the
         // reference's canonical Montgomery form first (exact conversion)
         std::vector<Xyzz9> raw(cnt);
         memcpy(raw.data(), src, (size_t)cnt * sizeof(Xyzz9));
+        Xyzz9 nraw[k16_scalar_classes::BITS];
+        if (pd.narrow) memcpy(nraw, src + k16_ctx::NARROW_OFF, pd.narrow * sizeof(Xyzz9));
         pop(); // the slot may be reused from here on
         std::vector<G1Xyzz> T(cnt);
         const std::function<void(unsigned)> prep = [&](unsigned w) {
@@ -365,6 +437,11 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
             flat_combine_host<Fq>(ctx, T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
         else
             horner_host<Fq>(ctx, T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+        if (pd.narrow) {
+            G1Xyzz S[k16_scalar_classes::BITS];
+            for (unsigned b = 0; b < pd.narrow; b++) S[b] = xyzz9_to_canonical(nraw[b]);
+            add_narrow(r, S);
+        }
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G1Aff a = to_affine(r);
@@ -373,15 +450,17 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
     } else {
         std::vector<Xyzz<Fq2n>> raw(cnt);
         memcpy(raw.data(), src, (size_t)cnt * sizeof(Xyzz<Fq2n>));
+        Xyzz<Fq2n> nraw[k16_scalar_classes::BITS];
+        if (pd.narrow) memcpy((void*)nraw, src + k16_ctx::NARROW_OFF, pd.narrow * sizeof(Xyzz<Fq2n>));
         pop();
         std::vector<G2Xyzz> T(cnt);
+        auto canon2 = [](const Xyzz<Fq2n>& p9) {
+            return p9.is_zero() ? G2Xyzz::zero()
+                                : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
+                                         fq2n_to_canonical(p9.zzz)};
+        };
         const std::function<void(unsigned)> prep = [&](unsigned w) {
-            for (unsigned i = w * (pd.nbits + 2); i < (w + 1) * (pd.nbits + 2); i++) {
-                const Xyzz<Fq2n>& p9 = raw[i];
-                T[i] = p9.is_zero() ? G2Xyzz::zero()
-                                    : G2Xyzz{fq2n_to_canonical(p9.x), fq2n_to_canonical(p9.y), fq2n_to_canonical(p9.zz),
-                                             fq2n_to_canonical(p9.zzz)};
-            }
+            for (unsigned i = w * (pd.nbits + 2); i < (w + 1) * (pd.nbits + 2); i++) T[i] = canon2(raw[i]);
         };
         g_window_prep = &prep;
         struct Clear {
@@ -389,6 +468,11 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
         } clear;
         G2Xyzz r;
         horner_host<Fq2>(ctx, T.data(), pd.w, pd.c, pd.nbits, pd.mlog, &r);
+        if (pd.narrow) {
+            G2Xyzz S[k16_scalar_classes::BITS];
+            for (unsigned b = 0; b < pd.narrow; b++) S[b] = canon2(nraw[b]);
+            add_narrow(r, S);
+        }
         if (h_out_xyzz) memcpy(h_out_xyzz, &r, sizeof r);
         if (h_out_affine) {
             G2Aff a = to_affine(r);

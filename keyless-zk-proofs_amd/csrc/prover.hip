@@ -318,6 +318,12 @@ struct k16_prover {
     std::vector<uint8_t> last_h;
     int warmup_rc = 0; // status of the create-time warm-up proof (k16_prover_warmup_status)
     struct WitnessPacker* packer = nullptr; // compact witness upload (see k_wtns_expand_*); null: plain copy
+    // scalar classes of the witness (msm_classes.hip): one classification per proof serves A, B1, B2 and C.  zmask[t] = the
+    // (0,0) rows of table t (A, B1, B2, C); tables with equal masks share a list set (set_of[t])
+    k16_scalar_classes* cls = nullptr;
+    void*               d_zmask[4] = {nullptr, nullptr, nullptr, nullptr};
+    const void*         set_mask[4] = {nullptr, nullptr, nullptr, nullptr};
+    int                 set_of[4] = {0, 0, 0, 0}, n_sets = 0;
 };
 
 // Host side of the compact upload: the context's host threads (k16_ctx_pool) each scan a contiguous range of the witness.
@@ -370,6 +376,12 @@ struct WitnessPacker {
             if (overflow[t]) return false;
         return true;
     }
+    uint64_t wide_total() const
+    {
+        uint64_t s = 0;
+        for (unsigned t = 0; t < n_threads; t++) s += count[t];
+        return s;
+    }
     ~WitnessPacker()
     {
         if (h_narrow) (void)hipHostFree(h_narrow);
@@ -403,6 +415,29 @@ static WitnessPacker* packer_create(k16_ctx* ctx, uint32_t n_vars)
     return w;
 }
 
+// number of witness values >= 256 (plain-copy path: small circuits, or a witness too wide for the compact upload)
+static uint64_t count_wide_host(k16_ctx* ctx, const void* h_wtns, uint64_t n)
+{
+    const uint8_t* src = (const uint8_t*)h_wtns;
+    auto range = [&](uint64_t lo, uint64_t hi) {
+        uint64_t c = 0;
+        for (uint64_t i = lo; i < hi; i++) {
+            uint64_t w[4];
+            memcpy(w, src + i * 32, 32);
+            c += ((w[0] >> 8) | w[1] | w[2] | w[3]) != 0;
+        }
+        return c;
+    };
+    k16_host_pool* pool = n >= (1u << 16) ? k16_ctx_pool(ctx) : nullptr;
+    if (!pool) return range(0, n);
+    const unsigned        T = pool->width();
+    std::vector<uint64_t> part(T, 0);
+    pool->run(T, [&](unsigned t) { part[t] = range(n * t / T, n * (t + 1) / T); });
+    uint64_t c = 0;
+    for (uint64_t v : part) c += v;
+    return c;
+}
+
 static void prover_free(k16_prover* p)
 {
     if (!p) return;
@@ -413,6 +448,9 @@ static void prover_free(k16_prover* p)
     if (p->st2) (void)hipStreamDestroy(p->st2);
     if (p->ev_w) (void)hipEventDestroy(p->ev_w);
     if (p->ev_h) (void)hipEventDestroy(p->ev_h);
+    for (void* m : p->d_zmask)
+        if (m) (void)hipFree(m);
+    if (p->cls) k16_scalar_classes_destroy(p->cls);
     delete p->packer;
     delete p;
 }
@@ -618,6 +656,37 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // request (35 ms instead of 8 through the facade).  Its outcome does not decide anything: a device that cannot prove
     // says so on the first real request.  Not under fault injection, whose counter counts requests.
     p->packer = packer_create(ctx, p->n_vars);
+    // scalar classes for the four witness MSMs: the (0,0) rows of each table, tables with the same rows sharing a set
+    if (!getenv("K16_NO_CLASSES")) {
+        const size_t         mb = ((size_t)p->n_vars + 63) / 64 * 8;
+        const void*          tab[4] = {p->d_A, p->d_B1, p->d_B2, p->d_C};
+        const int            grp[4] = {K16_G1, K16_G1, K16_G2, K16_G1};
+        std::vector<uint8_t> hm[4];
+        for (int t = 0; t < 4; t++) {
+            K16_HIP_P(ctx, hipMalloc(&p->d_zmask[t], mb), p);
+            if ((rc = k16_msm_zero_row_mask(ctx, grp[t], tab[t], p->n_vars, p->d_zmask[t]))) {
+                prover_free(p);
+                return rc;
+            }
+            hm[t].resize(mb);
+            K16_HIP_P(ctx, hipMemcpyAsync(hm[t].data(), p->d_zmask[t], mb, hipMemcpyDeviceToHost, st), p);
+        }
+        K16_HIP_P(ctx, hipStreamSynchronize(st), p);
+        for (int t = 0; t < 4; t++) {
+            int s = -1;
+            for (int u = 0; u < t && s < 0; u++)
+                if (hm[u] == hm[t]) s = p->set_of[u];
+            if (s < 0) {
+                s              = p->n_sets++;
+                p->set_mask[s] = p->d_zmask[t];
+            }
+            p->set_of[t] = s;
+        }
+        if ((rc = k16_scalar_classes_create(ctx, p->n_vars, p->n_sets, &p->cls))) {
+            prover_free(p);
+            return rc;
+        }
+    }
 #ifdef K16_TESTING
     const bool fault_env = getenv("K16_FAULT_INJECT") != nullptr;
 #else
@@ -772,8 +841,10 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count());
     };
     K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
+    int64_t n_wide = -1; // wide (>= 256) witness values, counted on the host: the classification then needs no round trip
     if (p->packer && p->packer->pack(h_wtns)) {
         WitnessPacker* w = p->packer;
+        n_wide           = (int64_t)w->wide_total();
         WideLists      L;
         L.n_lists = w->n_threads;
         uint32_t most = 0;
@@ -789,6 +860,11 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         K16_HIP(ctx, hipGetLastError());
     } else {
         K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
+        if (p->cls) n_wide = (int64_t)count_wide_host(ctx, h_wtns, p->n_vars);
+    }
+    if (p->cls) {
+        ctx->cur_lane = 0;
+        if ((rc = k16_scalar_classes_build(ctx, p->cls, p->d_wtns, p->n_vars, p->set_mask, p->n_sets, n_wide))) return rc;
     }
 
     // The reference overlaps the four witness MSMs with the a/b/c chain through std::async
@@ -851,7 +927,24 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     } lane_reset{ctx};
     hipStream_t s1 = k16_lane_stream(ctx, 1);
     K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_w, 0)); // witness upload (lane 0's stream)
-    {
+    if (p->cls) {
+        // scalar classes (msm_classes.hip): masked sums for the wires below 256, the ordinary MSM over the few wide ones --
+        // whose bucket sort (lane 0's, window size chosen for THEIR number) serves all four tables as before.  B2 first: its
+        // G2 arithmetic and its host combine are the longest of the four
+        ctx->cur_lane = 0;
+        if ((rc = k16_msm_enqueue_classified(ctx, K16_G1, p->d_A, p->cls, p->set_of[0]))) return rc;
+        ctx->cur_lane        = 2;
+        ctx->reuse_sort      = true;
+        ctx->reuse_sort_lane = 0;
+        if ((rc = k16_msm_enqueue_classified(ctx, K16_G2, p->d_B2, p->cls, p->set_of[2]))) return rc;
+        ctx->cur_lane        = 1;
+        ctx->reuse_sort      = true;
+        ctx->reuse_sort_lane = 0;
+        if ((rc = k16_msm_enqueue_classified(ctx, K16_G1, p->d_C, p->cls, p->set_of[3]))) return rc;
+        ctx->cur_lane   = 0;
+        ctx->reuse_sort = true;
+        if ((rc = k16_msm_enqueue_classified(ctx, K16_G1, p->d_B1, p->cls, p->set_of[1]))) return rc;
+    } else {
         ForcedC fc(ctx, wc);
         ctx->cur_lane = 0;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars))) return rc;
@@ -903,14 +996,24 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     pi_a          = h_madd(pi_a, p->alpha1);
     pi_a          = h_add(pi_a, d1_r);
     G1Xyzz a_s    = h_mul(pi_a, s_std);
-    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_c, nullptr))) return rc; // enqueue order: A, C, B1, B2, H
+    auto finish_b2 = [&]() -> int {
+        // B2's combine is 1.2 ms of G2 arithmetic on one thread: on the pool when it is the classified path's (enqueued
+        // second, so that it runs under the GPU's H MSM)
+        ctx->parallel_combine = p->cls != nullptr;
+        const int r2          = k16_msm_finish_group(ctx, K16_G2, &pi_b, nullptr);
+        ctx->parallel_combine = false;
+        if (r2) return r2;
+        pi_b = h_madd(pi_b, p->beta2);
+        pi_b = h_add(pi_b, d2_s);
+        return K16_OK;
+    };
+    if (p->cls && (rc = finish_b2())) return rc; // enqueue order: A, B2, C, B1, H  (without classes: A, C, B1, B2, H)
+    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_c, nullptr))) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pib1, nullptr))) return rc;
     pib1          = h_madd(pib1, p->beta1);
     pib1          = h_add(pib1, d1_s);
     G1Xyzz b1_r   = h_mul(pib1, r_std);
-    if ((rc = k16_msm_finish_group(ctx, K16_G2, &pi_b, nullptr))) return rc;
-    pi_b = h_madd(pi_b, p->beta2);
-    pi_b = h_add(pi_b, d2_s);
+    if (!p->cls && (rc = finish_b2())) return rc;
     ht("B2 finished");
     // pi_a and pi_b are final: their affine form and decimal strings are made while the GPU still works on the H MSM
     const G1Aff A = to_affine(pi_a);

@@ -35,6 +35,7 @@ SYMBOLS = [
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
+    "k16_msm_zero_row_mask", "k16_scalar_classes_create", "k16_scalar_classes_destroy", "k16_scalar_classes_build", "k16_scalar_classes_counts", "k16_msm_enqueue_classified",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
@@ -92,6 +93,13 @@ def load():
     L.k16_msm_set_window_bits.argtypes = [vp, u32]
     L.k16_msm_set_lane.argtypes = [vp, i32]
     L.k16_points_sum.argtypes = [i32, vp, u64, vp, vp]
+    L.k16_msm_zero_row_mask.argtypes = [vp, i32, vp, u64, vp]
+    L.k16_scalar_classes_create.argtypes = [vp, u64, i32, C.POINTER(vp)]
+    L.k16_scalar_classes_destroy.argtypes = [vp]
+    L.k16_scalar_classes_destroy.restype = None
+    L.k16_scalar_classes_build.argtypes = [vp, vp, vp, u64, C.POINTER(vp), i32, C.c_int64]
+    L.k16_scalar_classes_counts.argtypes = [vp, vp, vp]
+    L.k16_msm_enqueue_classified.argtypes = [vp, i32, vp, vp, i32]
     L.k16_ntt.argtypes = [vp, vp, u64, u64, i32]
     L.k16_ntt_host.argtypes = [vp, vp, u64, u64, i32]
     L.k16_synth_points.argtypes = [vp, i32, u64, u64, vp]
@@ -242,6 +250,35 @@ class Context:
 
     def msm_enqueue_fixed_base(self, group, d_table, d_scalars, n):
         self._chk(self.L.k16_msm_enqueue_fixed_base(self.h, group, d_table.ptr, d_scalars.ptr, n))
+
+    # ---- scalar-class MSM (witness-like scalars)
+    def zero_row_mask(self, group, d_rows, n):
+        d = self.alloc(max((n + 63) // 64 * 8, 16))
+        self._chk(self.L.k16_msm_zero_row_mask(self.h, group, d_rows.ptr, n, d.ptr))
+        self.sync()
+        return d
+
+    def classes_create(self, max_n, max_sets=1):
+        h = C.c_void_p()
+        self._chk(self.L.k16_scalar_classes_create(self.h, max_n, max_sets, C.byref(h)))
+        return h
+
+    def classes_destroy(self, cls):
+        self.L.k16_scalar_classes_destroy(cls)
+
+    def classes_build(self, cls, d_scalars, n, masks=None, n_wide_bound=-1):
+        """masks: list of DeviceBuffer / None, one per set (None: one set, no zero rows)."""
+        masks = masks if masks is not None else [None]
+        arr = (C.c_void_p * len(masks))(*[(m.ptr if m is not None else None) for m in masks])
+        self._chk(self.L.k16_scalar_classes_build(self.h, cls, d_scalars.ptr if d_scalars else None, n, arr, len(masks), n_wide_bound))
+
+    def classes_counts(self, cls, n_sets):
+        out = np.zeros(n_sets * 8 + 1, dtype=np.uint32)
+        self._chk(self.L.k16_scalar_classes_counts(self.h, cls, _p(out)))
+        return out
+
+    def msm_enqueue_classified(self, group, d_prepared, cls, set_index=0):
+        self._chk(self.L.k16_msm_enqueue_classified(self.h, group, d_prepared.ptr if d_prepared else None, cls, set_index))
 
     def msm_finish(self, group):
         x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)

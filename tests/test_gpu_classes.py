@@ -1,0 +1,217 @@
+"""-m gpu : the scalar-class MSM (k16_scalar_classes_*, k16_msm_enqueue_classified; csrc/msm_classes.hip and the
+"Scalar-class MSM" part of csrc/msm_kernels.inc) through the C ABI against the CPU oracle's multiexp on the SAME bases and
+scalars.  It replaces what the reference's zero-digit skip (multiexp.cpp:59-65) does for the four witness MSMs of
+groth16.cpp:88-112, so the cases are the witness's: zeros, ones, bytes, field elements, class boundaries, (0,0) rows."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import pymodel as pm
+from gpu_common import np_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import k16
+    c = k16.Context(0)
+    yield c
+    c.close()
+
+
+def _ints_to_scalars(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def _classified(ctx, group, bases, scalars, use_mask=True, bound=-1, sets=1):
+    """bases: (n, AFF) zkey format; scalars (n, 32).  Returns the affine result bytes of the classified MSM."""
+    n = scalars.shape[0]
+    d_b = ctx.to_device(bases)
+    d_p = ctx.bases_prepare(group, d_b, n)
+    d_s = ctx.to_device(scalars)
+    cls = ctx.classes_create(max(n, 1), sets)
+    try:
+        mask = ctx.zero_row_mask(group, d_p, n) if (use_mask and n) else None
+        ctx.classes_build(cls, d_s, n, [mask] + [None] * (sets - 1), bound)
+        ctx.msm_enqueue_classified(group, d_p, cls, 0)
+        _, aff = ctx.msm_finish(group)
+        ctx.sync()
+    finally:
+        ctx.classes_destroy(cls)
+        for d in (d_b, d_p, d_s):
+            d.free()
+        if mask is not None:
+            mask.free()
+    return aff
+
+
+def _check(ctx, group, bases, scalars, **kw):
+    got = _classified(ctx, group, bases, scalars, **kw)
+    _, want = ol.msm(group, bases, scalars, nthreads=4)
+    assert got == want
+
+
+@pytest.mark.parametrize("group", [0, 1])
+@pytest.mark.parametrize("kind", ["zeros", "ones", "witness", "uniform", "full256"])
+def test_classified_msm_distributions(ctx, group, kind):
+    n = 5000 if group == 0 else 1500
+    _check(ctx, group, ol.gen_points(group, 5, n), np_scalars(11, n, kind))
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_classified_msm_all_bytes(ctx, group):
+    n = 6000 if group == 0 else 1200
+    rs = np.random.RandomState(5)
+    s = np.zeros((n, 32), dtype=np.uint8)
+    s[:, 0] = rs.randint(2, 256, size=n)
+    _check(ctx, group, ol.gen_points(group, 9, n), s)
+    s[:, 0] = 255            # every wire in all eight lists
+    _check(ctx, group, ol.gen_points(group, 9, n), s)
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_classified_msm_class_boundaries(ctx, group):
+    """values 0, 1, 2, 127, 128, 255 (narrow) and 256, 257, 2^16, 2^253, r-1, r, 2^256-1 (wide) side by side"""
+    vals = [0, 1, 2, 3, 127, 128, 129, 254, 255, 256, 257, 511, 512, 65535, 65536, (1 << 64) - 1, 1 << 64, 1 << 128,
+            1 << 253, pm.R - 1, pm.R, pm.R + 1, (1 << 256) - 1]
+    vals = vals * 9
+    n = len(vals)
+    _check(ctx, group, ol.gen_points(group, 2, n), _ints_to_scalars(vals))
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4097])
+def test_classified_msm_sizes_around_the_tiles(ctx, n):
+    _check(ctx, 0, ol.gen_points(0, 1, n) if n else np.zeros((0, 64), np.uint8), np_scalars(n + 3, n, "witness"))
+
+
+@pytest.mark.parametrize("group", [0, 1])
+@pytest.mark.parametrize("use_mask", [True, False])
+def test_classified_msm_zero_rows_and_duplicates(ctx, group, use_mask):
+    """(0,0) rows under every class (skipped through the mask, or met by the additions without it), duplicate and negated
+    rows next to each other in every class (P + P and P - P inside the chains and the trees)"""
+    n = 3000 if group == 0 else 900
+    bases = ol.gen_points(group, 21, n).copy()
+    ab = bases.shape[1]
+    rs = np.random.RandomState(8)
+    s = np_scalars(31, n, "witness")
+    zero = rs.rand(n) < 0.4
+    bases[zero] = 0
+    # duplicates: runs of the same point, and a point next to its negation
+    for start in (10, 500, 501, 502, 777):
+        bases[start:start + 8] = bases[start]
+    for at in (200, 640):     # a point next to its negation, under a one and under a byte
+        k = at % n
+        bases[k] = ol.gen_points(group, 5000 + at, 1)[0]
+        x = ol.mul_scalar(group, bytes(bases[k]), pm.limbs(1))
+        bases[k + 1] = np.frombuffer(ol.pt_to_affine(group, ol.pt_op(group, ol.PT_NEG, x)), dtype=np.uint8)
+        s[k:k + 2, :] = 0
+        s[k:k + 2, 0] = 1 if at == 200 else 6
+    s[5:40, :] = 0
+    s[5:40, 0] = 1            # ones on top of duplicates
+    s[500:520, :] = 0
+    s[500:520, 0] = 7
+    s[770:790] = np_scalars(2, 20, "uniform")
+    assert ab in (64, 128)
+    _check(ctx, group, bases, s, use_mask=use_mask)
+
+
+def test_classified_msm_all_rows_zero(ctx):
+    n = 1000
+    _check(ctx, 0, np.zeros((n, 64), dtype=np.uint8), np_scalars(1, n, "witness"))
+
+
+def test_classified_msm_shares_one_classification_between_tables_and_groups(ctx):
+    """The prover's use: one build, four tables with three different (0,0) patterns on three lanes, results in enqueue
+    order; C-style table with a zero prefix."""
+    import k16
+    n = 20000
+    s = np_scalars(77, n, "witness")
+    rs = np.random.RandomState(3)
+    tabs = []
+    for t, group in enumerate([0, 0, 1, 0]):
+        b = ol.gen_points(group, 40 + t, n if group == 0 else 3000).copy()
+        if group == 1:   # G2 table over the first 3000 wires only: the rest are (0,0) rows
+            full = np.zeros((n, 128), dtype=np.uint8)
+            full[:3000] = b
+            b = full
+        if t in (1, 2):
+            z = rs.rand(n) < 0.5
+            b[z] = 0
+        if t == 3:
+            b[:2] = 0
+        tabs.append((group, b))
+    d_s = ctx.to_device(s)
+    d_tabs, masks = [], []
+    for group, b in tabs:
+        d_b = ctx.to_device(b)
+        d_p = ctx.bases_prepare(group, d_b, n)
+        d_b.free()
+        d_tabs.append(d_p)
+        masks.append(ctx.zero_row_mask(group, d_p, n))
+    cls = ctx.classes_create(n, 4)
+    n_wide = int((s[:, 1:].any(axis=1)).sum())
+    ctx.classes_build(cls, d_s, n, masks, n_wide)          # exact bound from the host, no read-back
+    counts = ctx.classes_counts(cls, 4)
+    assert counts[32] == n_wide
+    narrow = ~s[:, 1:].any(axis=1)
+    for t, (group, b) in enumerate(tabs):
+        nz = b.any(axis=1)
+        for bit in range(8):
+            assert counts[t * 8 + bit] == int((narrow & nz & (((s[:, 0] >> bit) & 1) == 1)).sum()), (t, bit)
+    for lane, t in ((0, 0), (1, 3), (0, 1), (2, 2)):
+        ctx.set_lane(lane)
+        ctx.msm_enqueue_classified(tabs[t][0], d_tabs[t], cls, t)
+    ctx.set_lane(0)
+    for t in (0, 3, 1, 2):
+        _, got = ctx.msm_finish(tabs[t][0])
+        _, want = ol.msm(tabs[t][0], tabs[t][1], s, nthreads=4)
+        assert got == want, t
+    ctx.sync()
+    ctx.classes_destroy(cls)
+    d_s.free()
+    for d in d_tabs + masks:
+        d.free()
+
+
+def test_classified_msm_bound_below_the_actual_count_fails_loudly(ctx):
+    import k16
+    n = 4000
+    s = np_scalars(5, n, "witness")
+    n_wide = int((s[:, 1:].any(axis=1)).sum())
+    assert n_wide > 10
+    bases = ol.gen_points(0, 6, n)
+    with pytest.raises(k16.K16Error) as e:
+        _classified(ctx, 0, bases, s, bound=n_wide - 3)
+    assert e.value.rc == -3
+    ctx.msm_abort_all()
+    # a generous bound is fine (unused rows hold zero scalars)
+    got = _classified(ctx, 0, bases, s, bound=n_wide + 100)
+    assert got == ol.msm(0, bases, s, nthreads=4)[1]
+    got = _classified(ctx, 0, bases, s, bound=n_wide)
+    assert got == ol.msm(0, bases, s, nthreads=4)[1]
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_classified_msm_witness_2p20_vs_oracle(ctx, group):
+    """BASELINE config 3's witness MSM shape at full table size."""
+    n = 1 << 20
+    s = np_scalars(123 + group, n, "witness")
+    d_b = ctx.synth_points(group, 0, n)
+    bases = d_b.download(np.uint8, (n, 64 if group == 0 else 128)).copy()
+    if group == 1:
+        bases[::2] = 0                # B2-like: half of the rows are (0,0)
+        d_b.upload(bases)
+    d_p = ctx.bases_prepare(group, d_b, n)
+    mask = ctx.zero_row_mask(group, d_p, n)
+    d_s = ctx.to_device(s)
+    cls = ctx.classes_create(n, 1)
+    ctx.classes_build(cls, d_s, n, [mask], -1)
+    ctx.msm_enqueue_classified(group, d_p, cls, 0)
+    _, got = ctx.msm_finish(group)
+    _, want = ol.msm(group, bases, s, nthreads=8)
+    assert got == want
+    ctx.sync()
+    ctx.classes_destroy(cls)
+    for d in (d_b, d_p, d_s, mask):
+        d.free()

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--facade", type=int, default=0,
                     help="also drive the C++ FullProver facade (tests/cpp/fullprover_harness.cpp) with this many threads over "
                          "a pool of as many provers on GPU 0 (K16_DEVICES=0,0,..)")
+    ap.add_argument("--no-stats", action="store_true", help="no per-stage HIP events inside the timed proofs")
     ap.add_argument("--concurrent", type=int, default=1, help="throughput mode: this many provers (own context, streams) share the GPU")
     args = ap.parse_args()
     n_vars = max(int(1343588 * args.scale), 8)
@@ -61,7 +62,7 @@ def main():
     wits = [synth_witness(n_vars, 100 + i) for i in range(min(args.proofs, 4))]
     prover.prove_mem(wits[0], r, s)  # warm-up: workspace allocation
     lat, dev = [], []
-    ctx.stats_enable(True)
+    ctx.stats_enable(not args.no_stats)
     ctx.stats_reset()
     t_all = time.perf_counter()
     for i in range(args.proofs):
