@@ -76,6 +76,10 @@ typedef struct k16_prover k16_prover;
 int         k16_runtime_hw_queues(int n);
 /* number of HIP devices this process can use (0 without a device or runtime; never an error code) */
 int         k16_device_count(void);
+/* Host worker threads of the library: ONE pool per process, shared by all contexts and provers (the reference has one TBB
+ * arena per process, multiexp.cpp:46) -- K16_HOST_THREADS, default 3/4 of the CPUs the process may use, at most 12, counting
+ * the calling thread.  Returns the number of workers started so far (0 before the first prover is created). */
+int         k16_host_threads(void);
 
 /* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
 int         k16_ctx_create(int device, k16_ctx** out);

@@ -18,60 +18,89 @@
 #include <functional>
 #include <thread>
 
-// A few host threads for the two host-side loops that sit on a proof's critical path: packing the witness for the compact
-// upload (prover.hip) and combining the per-window partial sums of the last MSM (msm_api.hip).  Workers sleep on a
-// condition variable between jobs; run() hands out task numbers from an atomic counter, the caller takes part.
+// Host threads for the host-side loops that sit on a proof's critical path: packing the witness for the compact upload
+// (prover.hip) and combining the per-window partial sums of an MSM (msm_api.hip).  ONE pool per PROCESS (round 4): a pool
+// per context -- round 3 -- meant 12 threads per prover, i.e. 350 idle-or-fighting threads under a service that keeps four
+// provers on each of eight GPUs; the reference has one TBB arena per process (multiexp.cpp:46).  Several callers (provers
+// of different contexts) may run jobs at once: a job is a task counter on its caller's stack, the workers take tasks from
+// the oldest job that still has some, and the caller works on its own job too, so a job never waits for a free worker.
 struct k16_host_pool {
-    std::vector<std::thread>      workers;
-    std::mutex                    mu, run_mu;
-    std::condition_variable       cv_go, cv_done;
-    uint64_t                      gen = 0;
-    unsigned                      pending = 0;
-    bool                          quit = false;
-    std::function<void(unsigned)> job;
-    std::atomic<unsigned>         next{0};
-    unsigned                      n_tasks = 0;
+    struct Job {
+        const std::function<void(unsigned)>* f = nullptr;
+        unsigned                             n = 0;
+        unsigned                             next = 0;      // guarded by mu
+        std::atomic<unsigned>                done{0};
+    };
+    std::vector<std::thread> workers;
+    std::mutex               mu;
+    std::condition_variable  cv_go, cv_done;
+    std::vector<Job*>        jobs; // jobs with unclaimed tasks, oldest first
+    bool                     quit = false;
     explicit k16_host_pool(unsigned n_workers)
     {
         for (unsigned t = 0; t < n_workers; t++) workers.emplace_back([this] { loop(); });
     }
     unsigned width() const { return (unsigned)workers.size() + 1; }
-    void     drain()
+    // next task of job j (mu held); removes the job from the list when it hands out the last one
+    bool take(Job* j, unsigned* t)
     {
-        for (unsigned t; (t = next.fetch_add(1)) < n_tasks;) job(t);
+        if (j->next >= j->n) return false;
+        *t = j->next++;
+        if (j->next == j->n) {
+            for (size_t i = 0; i < jobs.size(); i++)
+                if (jobs[i] == j) {
+                    jobs.erase(jobs.begin() + i);
+                    break;
+                }
+        }
+        return true;
+    }
+    void finish_one(Job* j)
+    {
+        const unsigned n = j->n; // the job may be gone as soon as the count below reaches n
+        if (j->done.fetch_add(1) + 1 == n) {
+            std::lock_guard<std::mutex> lk(mu);
+            cv_done.notify_all();
+        }
     }
     void loop()
     {
-        uint64_t seen = 0;
         for (;;) {
+            Job*     j = nullptr;
+            unsigned t = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                cv_go.wait(lk, [&] { return quit || !jobs.empty(); });
                 if (quit) return;
-                seen = gen;
+                j = jobs.front();
+                if (!take(j, &t)) continue;
             }
-            drain();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--pending == 0) cv_done.notify_one();
-            }
+            (*j->f)(t);
+            finish_one(j);
         }
     }
-    void run(unsigned tasks, std::function<void(unsigned)> f) // f(task) for task in [0, tasks); returns when all are done
+    void run(unsigned tasks, const std::function<void(unsigned)>& f) // f(task) for task in [0, tasks); returns when all are done
     {
-        std::lock_guard<std::mutex> one(run_mu);
+        if (tasks == 0) return;
+        Job j;
+        j.f = &f;
+        j.n = tasks;
         {
             std::lock_guard<std::mutex> lk(mu);
-            job     = std::move(f);
-            n_tasks = tasks;
-            next.store(0);
-            pending = (unsigned)workers.size();
-            gen++;
+            jobs.push_back(&j);
         }
         cv_go.notify_all();
-        drain();
+        for (;;) {
+            unsigned t;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!take(&j, &t)) break;
+            }
+            f(t);
+            j.done.fetch_add(1);
+        }
         std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return pending == 0; });
+        cv_done.wait(lk, [&] { return j.done.load() == tasks; });
     }
     ~k16_host_pool()
     {
@@ -225,8 +254,6 @@ struct k16_ctx {
     unsigned    acc_dyn_grid  = 0; // K16_ACC_DYN: persistent accumulate grid of this many workgroups with dynamic chunk fetch
 
     std::map<uint32_t, k16_ntt_table> ntt_tables;
-    k16_host_pool*                    pool = nullptr; // created on first use (k16_ctx_pool), K16_HOST_THREADS wide
-    bool                              pool_tried = false;
     // the per-window combine of an MSM's partial sums runs on the host pool only when asked to (the prover does for the H MSM,
     // the last item on a proof's critical path; for MSMs whose combine overlaps GPU work, waking the pool only costs)
     bool                              parallel_combine = false;
@@ -250,7 +277,8 @@ struct k16_scalar_classes {
     hipEvent_t built    = nullptr;  // recorded behind the classification
 };
 
-// the context's host thread pool, or nullptr (K16_HOST_THREADS=1, or no thread could be started): callers then loop serially
+// the PROCESS's host thread pool (created on first use; K16_HOST_THREADS wide, default 3/4 of the usable CPUs, at most 12), or
+// nullptr (K16_HOST_THREADS=1, or no thread could be started): callers then loop serially
 k16_host_pool* k16_ctx_pool(k16_ctx* ctx);
 
 // Lane streams are created on first use: ROCm multiplexes a process's streams onto 4 hardware queues by default

@@ -118,7 +118,6 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
         for (auto* b : bufs)
             if (b->p) (void)hipFree(b->p);
     }
-    delete c->pool;
     for (auto& kv : c->ntt_tables)
         if (kv.second.roots) (void)hipFree(kv.second.roots);
     for (auto& kv : c->ntt_tables)
@@ -142,15 +141,18 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
     });
 }
 
-// Host threads of a context: three quarters of the CPUs the process may use (affinity mask), at most 12, or
-// K16_HOST_THREADS (K16_UPLOAD_THREADS is the older name).  Measured on a 16-CPU box, Keyless-shape proof: 1 thread
-// (plain witness copy) p50 7.0 ms, 4 threads 6.9-7.0, 8 threads 6.5, 12 threads 6.47.
-k16_host_pool* k16_ctx_pool(k16_ctx* ctx)
+// Host threads of the PROCESS: three quarters of the CPUs it may use (affinity mask), at most 12, or K16_HOST_THREADS
+// (K16_UPLOAD_THREADS is the older name) -- shared by every context (ctx.h).  Measured on a 16-CPU box, Keyless-shape proof:
+// 1 thread (plain witness copy) p50 7.0 ms, 4 threads 6.9-7.0, 8 threads 6.5, 12 threads 6.47.  The pool lives until the
+// process ends (its workers sleep on a condition variable between jobs).
+static k16_host_pool* g_host_pool       = nullptr;
+static bool           g_host_pool_tried = false;
+k16_host_pool* k16_ctx_pool(k16_ctx*)
 {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (ctx->pool || ctx->pool_tried) return ctx->pool;
-    ctx->pool_tried = true;
+    if (g_host_pool || g_host_pool_tried) return g_host_pool;
+    g_host_pool_tried = true;
     unsigned    want = 0;
     const char* e    = getenv("K16_HOST_THREADS");
     if (!e) e = getenv("K16_UPLOAD_THREADS");
@@ -164,11 +166,17 @@ k16_host_pool* k16_ctx_pool(k16_ctx* ctx)
     }
     if (want < 2) return nullptr;
     try {
-        ctx->pool = new k16_host_pool(want - 1);
+        g_host_pool = new k16_host_pool(want - 1);
     } catch (...) {
-        ctx->pool = nullptr;
+        g_host_pool = nullptr;
     }
-    return ctx->pool;
+    return g_host_pool;
+}
+// worker threads of the process-wide pool (0 before its first use): the budget a service has to plan for is this plus the
+// threads that call into the library
+extern "C" int k16_host_threads(void)
+{
+    return g_host_pool ? (int)g_host_pool->workers.size() : 0;
 }
 
 hipStream_t k16_lane_stream(k16_ctx* ctx, int lane)

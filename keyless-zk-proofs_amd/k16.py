@@ -31,7 +31,7 @@ ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -
 
 # every symbol include/k16.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "k16_runtime_hw_queues", "k16_device_count", "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
+    "k16_runtime_hw_queues", "k16_device_count", "k16_host_threads", "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
