@@ -81,7 +81,12 @@ int         k16_device_count(void);
  * the calling thread.  Returns the number of workers started so far (0 before the first prover is created). */
 int         k16_host_threads(void);
 
-/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ---- */
+/* ---- context: one per GPU (one process per GPU in multi-GPU runs) ----
+ * THREADING: a context (and every prover / key / classes object created from it) is for ONE caller thread at a time.  Two
+ * exceptions the library itself relies on: one thread may k16_msm_enqueue* while another k16_msm_finish*es (bench.py), and
+ * k16_verify_batch may be called from several threads -- its latency path (n <= 64) shares the context's staging area and is
+ * serialised inside the call.  Callers that want proofs in parallel use one context per prover (FullProver's K16_DEVICES
+ * pool does); all contexts of a process share one host-thread pool (k16_host_threads). */
 int         k16_ctx_create(int device, k16_ctx** out);
 void        k16_ctx_destroy(k16_ctx* ctx);
 const char* k16_last_error(const k16_ctx* ctx);
@@ -178,6 +183,10 @@ int  k16_scalar_classes_build(k16_ctx* ctx, k16_scalar_classes* cls, const void*
                               const void* const* d_zero_masks, int n_sets, int64_t n_wide_bound);
 int  k16_scalar_classes_counts(k16_ctx* ctx, const k16_scalar_classes* cls, uint32_t* out);
 int  k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set);
+/* The next k16_msm_enqueue / _prepared leaves the points whose bit is set in d_mask (k16_msm_zero_row_mask of its table, or
+ * the AND of the masks of several tables that will share the sort) out of its bucket sort: (0,0) rows add nothing, but as
+ * sorted entries they cost a lane of every addition they sit beside.  Covers one enqueue; n <= 2^24. */
+int  k16_msm_set_zero_row_mask(k16_ctx* ctx, const void* d_mask);
 /* A context has K16_MSM_LANES independent MSM lanes (HIP stream + workspace).  The next k16_msm_enqueue* uses the
  * selected lane; MSMs on different lanes may overlap on the GPU (their inputs must already be complete: uploads
  * through k16_h2d are).  k16_msm_finish still returns results in enqueue order.  Default lane 0. */

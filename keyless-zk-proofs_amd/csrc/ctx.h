@@ -169,6 +169,7 @@ struct k16_ctx {
         const void* sorted_scalars = nullptr;
         uint64_t    sorted_n = 0;
         unsigned    sorted_c = 0;
+        const uint64_t* sorted_skip = nullptr; // zero-row mask that sort was made with
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
@@ -199,8 +200,10 @@ struct k16_ctx {
     // One thread may enqueue while another finishes (bench.py does: launches on a slow host then overlap the wait for the
     // GPU): the ring bookkeeping and the host timers are guarded; everything else an enqueue touches is its own.
     std::mutex ring_mu;
+    std::mutex verify_mu; // the latency path of k16_verify_batch: pinned staging area + the key's small device buffers
     Pend       pend[PEND_SLOTS];
     int        pend_head = 0, pend_count = 0; // ring: oldest at pend_head
+    int        pend_reserved = 0;             // classified MSMs whose narrow part is enqueued and whose wide part is still to come (k16_msm_classified_phase)
     hipEvent_t pend_ev[PEND_SLOTS] = {};
     int        enq_slot = 0;                  // staging slot of the MSM being enqueued
     unsigned   pend_mlog = 0;
@@ -224,6 +227,8 @@ struct k16_ctx {
     // table-row indirection of the NEXT bucket sort (consumed by it): the sort's scalars are a compacted subset, point k of
     // it is row remap_next[k] of the tables (k16_msm_enqueue_classified: the wide scalars of a witness)
     const uint32_t* remap_next = nullptr;
+    // zero-row mask of the NEXT bucket sort (consumed by it; an MSM that REUSES a sort must name the mask it was made with)
+    const uint64_t* skip_next = nullptr;
     // K16_SERIALIZE_ACC=1 (bench.py sets it): a lane's bucket accumulation waits for the previous lane's.  Two of these
     // chip-filling kernels never overlap anyway (kernel traces: the second starts when the first ends), so nothing is
     // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence

@@ -17,8 +17,8 @@ int k16_msm_prepare_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_ou
 int k16_msm_prepare_g2(k16_ctx* ctx, const void* d_bases, uint64_t n, void* d_out, hipStream_t st);
 int k16_msm_fixed_tables_g1(k16_ctx* ctx, const void* d_bases, uint64_t n, unsigned c, unsigned W, void* d_table);
 int k16_msm_enqueue_fixed_g1(k16_ctx* ctx, const void* d_table, const void* d_scalars, uint64_t n, unsigned c);
-int k16_msm_enqueue_classified_g1(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c, bool* has_wide);
-int k16_msm_enqueue_classified_g2(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c, bool* has_wide);
+int k16_msm_enqueue_classified_g1(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c, bool* has_wide, int phase);
+int k16_msm_enqueue_classified_g2(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c, bool* has_wide, int phase);
 
 namespace {
 constexpr unsigned MAX_C = 16;
@@ -200,6 +200,18 @@ extern "C" int k16_msm_set_lane(k16_ctx* ctx, int lane)
     });
 }
 
+// The next k16_msm_enqueue* leaves the points whose mask bit is set out of its bucket sort (k16_msm_zero_row_mask of the
+// table: (0,0) rows add nothing, curve.cpp:185-250, but as sorted entries they cost a lane of every addition they sit
+// beside).  One call covers one enqueue.  n <= 2^24, not for fixed-base tables.
+extern "C" int k16_msm_set_zero_row_mask(k16_ctx* ctx, const void* d_mask)
+{
+    return k16_guard(ctx, [&]() -> int {
+    if (!ctx) return K16_ERR_ARG;
+    ctx->skip_next = (const uint64_t*)d_mask;
+    return K16_OK;
+    });
+}
+
 extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
 {
     return k16_guard(ctx, [&]() -> int {
@@ -291,9 +303,10 @@ extern "C" int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_p
 }
 // Scalar-class MSM of one prepared table (msm_kernels.inc "Scalar-class MSM", msm_classes.hip): masked sums of the wires
 // below 256 + the ordinary MSM over the compacted wide scalars; results through k16_msm_finish like any other MSM.
-extern "C" int k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set)
+// phase 0: all of it.  The prover splits it: phase 1 (masked sums only; a staging slot is reserved) for all its tables first,
+// then phase 2 (wide part, the MSM joins the result queue) in the same order.
+int k16_msm_classified_phase(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set, int phase)
 {
-    return k16_guard(ctx, [&]() -> int {
     if (!ctx || !cls || cls->ctx != ctx || (group != K16_G1 && group != K16_G2) || set < 0 || set >= cls->n_sets ||
         (cls->n && !d_prepared))
         return K16_ERR_ARG;
@@ -302,11 +315,13 @@ extern "C" int k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d
     int idx;
     {
         std::lock_guard<std::mutex> lk(ctx->ring_mu);
-        if (ctx->pend_count == k16_ctx::PEND_SLOTS) {
+        const int ahead = phase == 1 ? ctx->pend_reserved : 0; // phase 2 completes the OLDEST reservation: the next ring position
+        if (ctx->pend_count + ahead >= k16_ctx::PEND_SLOTS || (phase == 2 && ctx->pend_reserved == 0)) {
             ctx->err = "k16_msm_enqueue: too many MSMs in flight; call k16_msm_finish";
             return K16_ERR_ARG;
         }
-        idx = (ctx->pend_head + ctx->pend_count) % k16_ctx::PEND_SLOTS;
+        idx = (ctx->pend_head + ctx->pend_count + ahead) % k16_ctx::PEND_SLOTS;
+        if (phase == 1) ctx->pend_reserved++;
     }
     k16_ctx::Pend pd;
     pd.group = group;
@@ -324,8 +339,8 @@ extern "C" int k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d
         }
         ctx->enq_slot    = idx;
         bool has_wide    = false;
-        int  rc = group == K16_G1 ? k16_msm_enqueue_classified_g1(ctx, d_prepared, cls, set, c, &has_wide)
-                                  : k16_msm_enqueue_classified_g2(ctx, d_prepared, cls, set, c, &has_wide);
+        int  rc = group == K16_G1 ? k16_msm_enqueue_classified_g1(ctx, d_prepared, cls, set, c, &has_wide, phase)
+                                  : k16_msm_enqueue_classified_g2(ctx, d_prepared, cls, set, c, &has_wide, phase);
         if (rc) return rc;
         pd.cls    = cls;
         pd.narrow = k16_scalar_classes::BITS;
@@ -335,14 +350,24 @@ extern "C" int k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d
             pd.nbits = ctx->pend_nbits;
             pd.mlog  = ctx->pend_mlog;
         }
-        K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], k16_lane_stream(ctx, ctx->cur_lane)));
+        if (phase != 1) K16_HIP(ctx, hipEventRecord(ctx->pend_ev[idx], k16_lane_stream(ctx, ctx->cur_lane)));
     }
-    {
+    if (phase != 1) {
         std::lock_guard<std::mutex> lk(ctx->ring_mu);
         ctx->pend[idx] = pd;
         ctx->pend_count++;
+        if (phase == 2) ctx->pend_reserved--;
     }
     return K16_OK;
+}
+extern "C" int k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set)
+{
+    return k16_guard(ctx, [&]() -> int {
+    if (ctx && ctx->pend_reserved) {
+        ctx->err = "k16_msm_enqueue_classified: a split classified MSM is still open";
+        return K16_ERR_ARG;
+    }
+    return k16_msm_classified_phase(ctx, group, d_prepared, cls, set, 0);
     });
 }
 
@@ -518,6 +543,9 @@ extern "C" int k16_msm_abort_all(k16_ctx* ctx)
     ctx->reuse_sort_lane = -1;
     ctx->cur_lane        = 0;
     ctx->forced_seg      = 0;
+    ctx->pend_reserved   = 0;
+    ctx->remap_next      = nullptr;
+    ctx->skip_next       = nullptr;
     (void)hipSetDevice(ctx->device);
     for (auto& L : ctx->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);

@@ -88,7 +88,7 @@ int k16_msm_enqueue_fixed_g1(k16_ctx* ctx, const void* d_table, const void* d_sc
     return msm_enqueue_t<Eng9>(ctx, (const k16::G1Aff*)d_table, d_scalars, n, c, true);
 }
 int k16_msm_enqueue_classified_g1(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c,
-                                  bool* has_wide)
+                                  bool* has_wide, int phase)
 {
-    return msm_enqueue_classified_t<Eng9>(ctx, (const k16::G1Aff*)d_rows, cls, set, c, has_wide);
+    return msm_enqueue_classified_t<Eng9>(ctx, (const k16::G1Aff*)d_rows, cls, set, c, has_wide, phase);
 }

@@ -24,7 +24,7 @@ int k16_msm_enqueue_g2(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
     return msm_enqueue_t<Eng2n>(ctx, rows, d_scalars, n, c);
 }
 int k16_msm_enqueue_classified_g2(k16_ctx* ctx, const void* d_rows, const k16_scalar_classes* cls, int set, unsigned c,
-                                  bool* has_wide)
+                                  bool* has_wide, int phase)
 {
-    return msm_enqueue_classified_t<Eng2n>(ctx, (const k16::G2Aff*)d_rows, cls, set, c, has_wide);
+    return msm_enqueue_classified_t<Eng2n>(ctx, (const k16::G2Aff*)d_rows, cls, set, c, has_wide, phase);
 }

@@ -134,8 +134,8 @@ struct NttPtrs {
 //     dst[bitrev(i)] = X[(n - i) mod n] * shift9[i],   shift9[i] = 2^-k * g^i  (one table, one multiplication)
 // The tile is read mid-major for that store (the mid bits are the LOW bits of bitrev(i): runs of 2^K * 32 bytes in dst),
 // with one element of padding per tile row so that the LDS reads stay conflict-free.
-template <bool CONV_IN, bool CONV_OUT, bool TAIL>
-__global__ void __launch_bounds__(256) k_ntt_pass9(NttPtrs pp, const uint32_t* __restrict__ roots9, uint32_t s0, uint32_t K,
+template <bool CONV_IN, bool CONV_OUT, bool TAIL, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_t* __restrict__ roots9, uint32_t s0, uint32_t K,
                                                    uint32_t TL, uint32_t S, uint32_t logn, const Fr* __restrict__ shift9)
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
@@ -351,7 +351,7 @@ int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out)
 
 // the fused passes of one transform over `count` polynomials; tail_dst != nullptr: the last pass stores through the TAIL path
 static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn, k16_ntt_table* tab, bool packed9,
-                       Fr* const* tail_dst, const Fr* shift9, hipStream_t st)
+                       Fr* const* tail_dst, const Fr* shift9, hipStream_t st, uint32_t tile_log = 10)
 {
     NttPtrs pp = {};
     for (int i = 0; i < count; i++) {
@@ -360,23 +360,48 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
     }
     const uint64_t n  = 1ull << logn;
     uint32_t       s0 = 0;
+    // Tile size.  1024 elements (36 KB of LDS, four workgroups per CU): 21 stages are three passes (10 + 6 + 5).  2048
+    // elements (72 KB, two workgroups of 512 threads per CU): two passes (11 + 10) -- one load / store round trip and one
+    // fill-and-drain of the chip less per transform, at the price of 64-byte runs in the second pass (T = 2).  Measured in
+    // a proof (three polynomials per launch, 2^21): forward 455 + 588 us against 610 + 349 + 300; the TAIL pass of the
+    // inverse transforms needs a padded tile (110 KB, one workgroup per CU) and loses (1156 us against 393 + 450), so the
+    // inverse transforms keep the small tile (k16_ntt_coset_chain).
+    if (tail_dst) tile_log = 10;
+    const uint32_t TLMAX = tile_log == 11 ? 1u : 4u;
     while (s0 < logn) {
-        const uint32_t TL = s0 < 4 ? s0 : 4;                      // T = min(2^s0, 16) lo values per tile
-        const uint32_t K  = std::min<uint32_t>(logn - s0, 10 - TL); // <= 1024 elements per tile
+        const uint32_t TL = s0 < TLMAX ? s0 : TLMAX;                    // T = min(2^s0, 16) lo values per tile
+        const uint32_t K  = std::min<uint32_t>(logn - s0, tile_log - TL); // <= 2^tile_log elements per tile
         const bool     first = s0 == 0, last = s0 + K == logn;
         const bool     cin = !packed9 && first, cout = !packed9 && last, tail = tail_dst && last;
         const dim3     grid((unsigned)(n >> (K + TL)), (unsigned)count);
         const size_t   lds = (size_t)(((tail && TL) ? (1u << TL) + 1 : (1u << TL)) << K) * sizeof(Fr9);
+        const bool     big = lds > 48 * 1024; // 512 threads per workgroup, dynamic LDS above the default limit
+#define K16_NTT_LAUNCH(CI, CO, TA)                                                                                              \
+    do {                                                                                                                        \
+        if (big) {                                                                                                              \
+            static bool attr = false;                                                                                           \
+            if (!attr) {                                                                                                        \
+                (void)hipFuncSetAttribute((const void*)k_ntt_pass9<CI, CO, TA, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          128 * 1024);                                                                          \
+                attr = true;                                                                                                    \
+            }                                                                                                                   \
+            hipLaunchKernelGGL((k_ntt_pass9<CI, CO, TA, 512>), grid, dim3(512), lds, st, pp, tab->roots9, s0, K, TL, tab->s,    \
+                               logn, shift9);                                                                                   \
+        } else                                                                                                                  \
+            hipLaunchKernelGGL((k_ntt_pass9<CI, CO, TA, 256>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s,    \
+                               logn, shift9);                                                                                   \
+    } while (0)
         if (tail)
-            hipLaunchKernelGGL((k_ntt_pass9<false, false, true>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+            K16_NTT_LAUNCH(false, false, true);
         else if (cin && cout)
-            hipLaunchKernelGGL((k_ntt_pass9<true, true, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+            K16_NTT_LAUNCH(true, true, false);
         else if (cin)
-            hipLaunchKernelGGL((k_ntt_pass9<true, false, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+            K16_NTT_LAUNCH(true, false, false);
         else if (cout)
-            hipLaunchKernelGGL((k_ntt_pass9<false, true, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+            K16_NTT_LAUNCH(false, true, false);
         else
-            hipLaunchKernelGGL((k_ntt_pass9<false, false, false>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s, logn, shift9);
+            K16_NTT_LAUNCH(false, false, false);
+#undef K16_NTT_LAUNCH
         s0 += K;
     }
 }
@@ -400,7 +425,11 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
                                    s, tab->s);
         } else {
             Fr* one[1] = {d_a};
-            ntt_passes(ctx, one, 1, logn, tab, packed9 != 0, nullptr, nullptr, st);
+            static const uint32_t pub_tile = [] {
+                const char* e = getenv("K16_NTT_TILE_LOG");
+                return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 11u;
+            }();
+            ntt_passes(ctx, one, 1, logn, tab, packed9 != 0, nullptr, nullptr, st, logn >= 12 ? pub_tile : 10u);
         }
     }
     if (inverse && !skip_tail) {
@@ -435,8 +464,12 @@ int k16_ntt_coset_chain(k16_ctx* ctx, k16::Fr* const* src, k16::Fr* const* dst, 
         return K16_OK;
     }
     k16_stat_scope ss(ctx, "ntt", st);
+    static const uint32_t fwd_tile = [] {
+        const char* e = getenv("K16_NTT_TILE_LOG");
+        return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 11u;
+    }();
     ntt_passes(ctx, src, count, logn, tab, true, dst, shift9, st);
-    ntt_passes(ctx, dst, count, logn, tab, true, nullptr, nullptr, st);
+    ntt_passes(ctx, dst, count, logn, tab, true, nullptr, nullptr, st, logn >= 12 ? fwd_tile : 10u);
     K16_HIP(ctx, hipGetLastError());
     return K16_OK;
 }

@@ -324,6 +324,12 @@ struct k16_prover {
     void*               d_zmask[4] = {nullptr, nullptr, nullptr, nullptr};
     const void*         set_mask[4] = {nullptr, nullptr, nullptr, nullptr};
     int                 set_of[4] = {0, 0, 0, 0}, n_sets = 0;
+    // bucket path: rows that are (0,0) in every table a sort serves are left out of it (k16_msm_set_zero_row_mask).  d_skip_ac:
+    // zero in A and C (A's sort serves both); d_skip_b: zero in B1 and B2, which get a sort of their own (B2's lane) when
+    // that drops enough entries to pay for it -- otherwise all four share A's sort and d_skip_ac holds the rows zero in all
+    void* d_skip_ac = nullptr;
+    void* d_skip_b  = nullptr;
+    bool  b_sort    = false;
 };
 
 // Host side of the compact upload: the context's host threads (k16_ctx_pool) each scan a contiguous range of the witness.
@@ -450,6 +456,8 @@ static void prover_free(k16_prover* p)
     if (p->ev_h) (void)hipEventDestroy(p->ev_h);
     for (void* m : p->d_zmask)
         if (m) (void)hipFree(m);
+    if (p->d_skip_ac) (void)hipFree(p->d_skip_ac);
+    if (p->d_skip_b) (void)hipFree(p->d_skip_b);
     if (p->cls) k16_scalar_classes_destroy(p->cls);
     delete p->packer;
     delete p;
@@ -656,35 +664,70 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     // request (35 ms instead of 8 through the facade).  Its outcome does not decide anything: a device that cannot prove
     // says so on the first real request.  Not under fault injection, whose counter counts requests.
     p->packer = packer_create(ctx, p->n_vars);
-    // scalar classes for the four witness MSMs: the (0,0) rows of each table, tables with the same rows sharing a set
-    if (!getenv("K16_NO_CLASSES")) {
-        const size_t         mb = ((size_t)p->n_vars + 63) / 64 * 8;
+    // the (0,0) rows of the four witness tables (wires a constraint side never mentions): left out of the bucket sorts, and
+    // of the scalar classes' lists
+    {
+        const size_t         mw = ((size_t)p->n_vars + 63) / 64, mb = mw * 8;
         const void*          tab[4] = {p->d_A, p->d_B1, p->d_B2, p->d_C};
         const int            grp[4] = {K16_G1, K16_G1, K16_G2, K16_G1};
-        std::vector<uint8_t> hm[4];
+        std::vector<uint64_t> hm[4];
         for (int t = 0; t < 4; t++) {
             K16_HIP_P(ctx, hipMalloc(&p->d_zmask[t], mb), p);
             if ((rc = k16_msm_zero_row_mask(ctx, grp[t], tab[t], p->n_vars, p->d_zmask[t]))) {
                 prover_free(p);
                 return rc;
             }
-            hm[t].resize(mb);
+            hm[t].resize(mw);
             K16_HIP_P(ctx, hipMemcpyAsync(hm[t].data(), p->d_zmask[t], mb, hipMemcpyDeviceToHost, st), p);
         }
         K16_HIP_P(ctx, hipStreamSynchronize(st), p);
-        for (int t = 0; t < 4; t++) {
-            int s = -1;
-            for (int u = 0; u < t && s < 0; u++)
-                if (hm[u] == hm[t]) s = p->set_of[u];
-            if (s < 0) {
-                s              = p->n_sets++;
-                p->set_mask[s] = p->d_zmask[t];
-            }
-            p->set_of[t] = s;
+        std::vector<uint64_t> ac(mw), bb(mw);
+        uint64_t              n_b = 0;
+        for (size_t k = 0; k < mw; k++) {
+            ac[k] = hm[0][k] & hm[3][k];
+            bb[k] = hm[1][k] & hm[2][k];
+            n_b += (uint64_t)__builtin_popcountll(bb[k] & ~ac[k]);
         }
-        if ((rc = k16_scalar_classes_create(ctx, p->n_vars, p->n_sets, &p->cls))) {
-            prover_free(p);
-            return rc;
+        // A second sort (same scalars, B's rows left out; K16_B_SORT=1) pays in latency, not in throughput: measured on the
+        // synthetic Keyless-shape key (half of B1 / B2 (0,0)), three alternating runs of 60 proofs on one box: p50 5.88-6.00
+        // against 6.00-6.02 ms, but four provers sharing the GPU 161-163 against 165-168 proofs/s (the sort is memory
+        // traffic on top of what the other provers' sorts already move; the additions it saves were issue slots nobody was
+        // short of there) -- profiles/r04/ab_b_sort.log.  Off by default.
+        p->b_sort = getenv("K16_B_SORT") && atoi(getenv("K16_B_SORT")) != 0 && p->n_vars >= (1u << 17) && n_b >= p->n_vars / 8;
+        if (!p->b_sort)
+            for (size_t k = 0; k < mw; k++) ac[k] &= bb[k];
+        K16_HIP_P(ctx, hipMalloc(&p->d_skip_ac, mb), p);
+        K16_HIP_P(ctx, hipMalloc(&p->d_skip_b, mb), p);
+        K16_HIP_P(ctx, hipMemcpyAsync(p->d_skip_ac, ac.data(), mb, hipMemcpyHostToDevice, st), p);
+        K16_HIP_P(ctx, hipMemcpyAsync(p->d_skip_b, bb.data(), mb, hipMemcpyHostToDevice, st), p);
+        K16_HIP_P(ctx, hipStreamSynchronize(st), p);
+        if (getenv("K16_NO_SKIP_ZERO_ROWS")) {
+            (void)hipFree(p->d_skip_ac);
+            (void)hipFree(p->d_skip_b);
+            p->d_skip_ac = p->d_skip_b = nullptr;
+            p->b_sort    = false;
+        }
+        // scalar classes (msm_classes.hip): tables with equal masks share a list set
+        // (Off by default, K16_CLASSES=1: measured on the synthetic Keyless-shape key the two paths execute the same number of
+        // VALU instructions per proof -- 2.07 against 2.19 G wave-instructions, the additions of a witness MSM being one per
+        // non-zero digit either way -- and the bucket path, whose kernels start before the NTT passes fill the chip, ends its
+        // G2 MSM earlier: p50 5.95-6.03 against 6.06-6.08 ms, four provers 173-177 against 161-165 proofs/s, same box,
+        // profiles/r04/ab_witness_classes.log.)
+        if (getenv("K16_CLASSES") && atoi(getenv("K16_CLASSES")) != 0) {
+            for (int t = 0; t < 4; t++) {
+                int sidx = -1;
+                for (int u = 0; u < t && sidx < 0; u++)
+                    if (hm[u] == hm[t]) sidx = p->set_of[u];
+                if (sidx < 0) {
+                    sidx              = p->n_sets++;
+                    p->set_mask[sidx] = p->d_zmask[t];
+                }
+                p->set_of[t] = sidx;
+            }
+            if ((rc = k16_scalar_classes_create(ctx, p->n_vars, p->n_sets, &p->cls))) {
+                prover_free(p);
+                return rc;
+            }
         }
     }
 #ifdef K16_TESTING
@@ -770,6 +813,7 @@ static int fault_injected_now()
 static inline int fault_injected_now() { return 0; }
 #endif
 
+int k16_msm_classified_phase(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set, int phase);
 static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
                            char* out_json, size_t cap, float* device_ms);
 
@@ -794,12 +838,20 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
         // Whatever failed, nothing of this proof may stay behind: MSMs already enqueued are waited for and dropped (the
         // next prove would otherwise pop them as ITS results), the sort-reuse flags and the lane selection are reset,
         // and the chain stream is drained.  The error text of the failure is kept.
-        k16_ctx*          ctx = p->ctx;
-        const std::string err = ctx->err;
-        (void)k16_msm_abort_all(ctx);
+        k16_ctx* ctx = p->ctx;
+        std::string err;
+        try {
+            err = ctx->err; // (a second allocation failure here must not skip the clean-up below)
+        } catch (...) {
+        }
+        (void)k16_msm_abort_all(ctx); // overwrites ctx->err only when an MSM in flight failed itself
         if (p->st2) (void)hipStreamSynchronize(p->st2);
-        ctx->forced_c = 0;
-        ctx->err      = err;
+        ctx->forced_c         = 0;
+        ctx->parallel_combine = false;
+        try {
+            if (!err.empty()) ctx->err = err;
+        } catch (...) {
+        }
     }
     return rc;
     });
@@ -931,35 +983,56 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         // scalar classes (msm_classes.hip): masked sums for the wires below 256, the ordinary MSM over the few wide ones --
         // whose bucket sort (lane 0's, window size chosen for THEIR number) serves all four tables as before.  B2 first: its
         // G2 arithmetic and its host combine are the longest of the four
-        ctx->cur_lane = 0;
-        if ((rc = k16_msm_enqueue_classified(ctx, K16_G1, p->d_A, p->cls, p->set_of[0]))) return rc;
-        ctx->cur_lane        = 2;
-        ctx->reuse_sort      = true;
-        ctx->reuse_sort_lane = 0;
-        if ((rc = k16_msm_enqueue_classified(ctx, K16_G2, p->d_B2, p->cls, p->set_of[2]))) return rc;
-        ctx->cur_lane        = 1;
-        ctx->reuse_sort      = true;
-        ctx->reuse_sort_lane = 0;
-        if ((rc = k16_msm_enqueue_classified(ctx, K16_G1, p->d_C, p->cls, p->set_of[3]))) return rc;
-        ctx->cur_lane   = 0;
-        ctx->reuse_sort = true;
-        if ((rc = k16_msm_enqueue_classified(ctx, K16_G1, p->d_B1, p->cls, p->set_of[1]))) return rc;
+        // The masked sums of all four first (they then run beside the SpMV, whose lanes wait on gathers, not beside the NTT
+        // passes), the wide parts after, in the same order = the order of the results.
+        struct T {
+            int         lane, group, tab;
+            const void* rows;
+        } const order[4] = {{0, K16_G1, 0, p->d_A}, {2, K16_G2, 2, p->d_B2}, {1, K16_G1, 3, p->d_C}, {0, K16_G1, 1, p->d_B1}};
+        static const bool split = getenv("K16_NO_SPLIT_CLASSES") == nullptr;
+        for (int phase = split ? 1 : 0; phase <= (split ? 2 : 0); phase++)
+            for (int k = 0; k < 4; k++) {
+                ctx->cur_lane = order[k].lane;
+                if (phase != 1 && k > 0) {
+                    ctx->reuse_sort      = true; // lane 0's sort of the wide scalars (A's) serves every table
+                    ctx->reuse_sort_lane = 0;
+                }
+                if ((rc = k16_msm_classified_phase(ctx, order[k].group, order[k].rows, p->cls, p->set_of[order[k].tab], phase))) return rc;
+            }
     } else {
         ForcedC fc(ctx, wc);
-        ctx->cur_lane = 0;
+        const uint64_t* skip_ac = (const uint64_t*)p->d_skip_ac;
+        const uint64_t* skip_b  = p->b_sort ? (const uint64_t*)p->d_skip_b : skip_ac;
+        if (p->b_sort) {
+            // B2 (G2: the longest of the four) first, on lane 2, with a bucket sort of its own that leaves out the rows that
+            // are (0,0) in B1 and B2 -- half of them in a circuit whose wires mostly sit on one side of a constraint; as
+            // sorted entries they would cost a lane of every addition they sit beside.  It also starts without waiting for A's sort.
+            K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, 2), p->ev_w, 0));
+            ctx->cur_lane  = 2;
+            ctx->skip_next = skip_b;
+            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
+        }
+        ctx->cur_lane  = 0;
+        ctx->skip_next = skip_ac;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars))) return rc;
         ctx->cur_lane        = 1;
         ctx->reuse_sort      = true; // C is indexed by wire (see k16_prover_create_mem): same scalars, same sort
         ctx->reuse_sort_lane = 0;
+        ctx->skip_next       = skip_ac;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, p->n_vars))) return rc;
-        ctx->cur_lane   = 0;
-        ctx->reuse_sort = true;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
-        // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
-        ctx->cur_lane        = 2;
+        ctx->cur_lane        = 0;
         ctx->reuse_sort      = true;
-        ctx->reuse_sort_lane = 0;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
+        ctx->reuse_sort_lane = p->b_sort ? 2 : 0;
+        ctx->skip_next       = skip_b;
+        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
+        if (!p->b_sort) {
+            // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
+            ctx->cur_lane        = 2;
+            ctx->reuse_sort      = true;
+            ctx->reuse_sort_lane = 0;
+            ctx->skip_next       = skip_ac;
+            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
+        }
     }
     ht("A C B1 B2 enqueued");
     if (const int fault = fault_injected_now()) {
@@ -991,29 +1064,36 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     G1Xyzz d1_rs_neg = pneg(h_mul(d1, rs_b));
 
     ht("H enqueued + host blinding");
-    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_a, nullptr))) return rc;
-    ht("A finished");
-    pi_a          = h_madd(pi_a, p->alpha1);
-    pi_a          = h_add(pi_a, d1_r);
-    G1Xyzz a_s    = h_mul(pi_a, s_std);
     auto finish_b2 = [&]() -> int {
         // B2's combine is 1.2 ms of G2 arithmetic on one thread: on the pool when it is the classified path's (enqueued
         // second, so that it runs under the GPU's H MSM)
+        struct Reset {
+            k16_ctx* c;
+            ~Reset() { c->parallel_combine = false; }
+        } reset{ctx};
         ctx->parallel_combine = p->cls != nullptr;
         const int r2          = k16_msm_finish_group(ctx, K16_G2, &pi_b, nullptr);
-        ctx->parallel_combine = false;
         if (r2) return r2;
         pi_b = h_madd(pi_b, p->beta2);
         pi_b = h_add(pi_b, d2_s);
         return K16_OK;
     };
-    if (p->cls && (rc = finish_b2())) return rc; // enqueue order: A, B2, C, B1, H  (without classes: A, C, B1, B2, H)
+    // results come back in enqueue order: classes A, B2, C, B1, H; bucket path B2, A, C, B1, H with a sort of its own for B,
+    // A, C, B1, B2, H without
+    const bool b2_first = !p->cls && p->b_sort;
+    if (b2_first && (rc = finish_b2())) return rc;
+    if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_a, nullptr))) return rc;
+    ht("A finished");
+    pi_a          = h_madd(pi_a, p->alpha1);
+    pi_a          = h_add(pi_a, d1_r);
+    G1Xyzz a_s    = h_mul(pi_a, s_std);
+    if (p->cls && (rc = finish_b2())) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_c, nullptr))) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pib1, nullptr))) return rc;
     pib1          = h_madd(pib1, p->beta1);
     pib1          = h_add(pib1, d1_s);
     G1Xyzz b1_r   = h_mul(pib1, r_std);
-    if (!p->cls && (rc = finish_b2())) return rc;
+    if (!p->cls && !b2_first && (rc = finish_b2())) return rc;
     ht("B2 finished");
     // pi_a and pi_b are final: their affine form and decimal strings are made while the GPU still works on the H MSM
     const G1Aff A = to_affine(pi_a);
@@ -1025,9 +1105,14 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     pi_c = h_add(pi_c, a_s);
     pi_c = h_add(pi_c, b1_r);
     pi_c = h_add(pi_c, d1_rs_neg);
-    ctx->parallel_combine = true; // the H MSM's partial sums: the one combine nothing else runs beside
-    rc                    = k16_msm_finish_group(ctx, K16_G1, &pih, nullptr);
-    ctx->parallel_combine = false;
+    {
+        struct ParallelCombine { // the H MSM's partial sums: the one combine nothing else runs beside (reset on every exit)
+            k16_ctx* c;
+            explicit ParallelCombine(k16_ctx* cx) : c(cx) { c->parallel_combine = true; }
+            ~ParallelCombine() { c->parallel_combine = false; }
+        } pc(ctx);
+        rc = k16_msm_finish_group(ctx, K16_G1, &pih, nullptr);
+    }
     if (rc) return rc;
     ht("H finished");
     K16_HIP(ctx, hipStreamWaitEvent(st, ctx->pend_ev[(ctx->pend_head + k16_ctx::PEND_SLOTS - 1) % k16_ctx::PEND_SLOTS], 0));

@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(128) k_verify_coop(CoopDev D, const uint32_t* 
                 const uint32_t ntl  = valid ? (wlo >> 14) & 0x3f : 0u;
                 const uint32_t t0   = ((wlo >> 20) | ((whi & 0xfff) << 12)) - tb;
                 // limb-wise 64-bit accumulation on top of 2^15 p (keeps the total positive: the negative coefficients of a
-                // combination sum to at most COOP_MAX_COEF = 2^12 times values < 4p)
+                // combination sum to at most COOP_MAX_COEF = 2^12 times values < 5p: materialised linear atoms)
                 const uint32_t p0 = lb == 0 ? Fq9C::P[0] : lb == 3 ? Fq9C::P[3] : Fq9C::P[6];
                 const uint32_t p1 = lb == 0 ? Fq9C::P[1] : lb == 3 ? Fq9C::P[4] : Fq9C::P[7];
                 const uint32_t p2 = lb == 0 ? Fq9C::P[2] : lb == 3 ? Fq9C::P[5] : Fq9C::P[8];
@@ -668,7 +668,9 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
             auto up = [&](void** d, const void* h, size_t bytes) {
                 return hipMalloc(d, bytes ? bytes : 16) == hipSuccess && hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice) == hipSuccess;
             };
-            vk->coop = vk->lds_bytes <= 160 * 1024 &&
+            hipFuncAttributes fa{};
+            const size_t      static_lds = hipFuncGetAttributes(&fa, (const void*)k_verify_coop<false>) == hipSuccess ? fa.sharedSizeBytes : 4096;
+            vk->coop = vk->lds_bytes + static_lds <= 160 * 1024 &&
                        up((void**)&vk->d_words, P->words.data(), P->words.size() * 8) &&
                        up((void**)&vk->d_terms, P->terms.data(), P->terms.size() * 4) &&
                        up((void**)&vk->d_hdr, hdr.data(), hdr.size() * 4) && up((void**)&vk->d_chunks, chunks.data(), chunks.size() * 4) &&
@@ -732,6 +734,10 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
     const uint8_t* dp     = (const uint8_t*)ctx->pinned_dev + (size_t)k16_ctx::PEND_SLOTS * k16_ctx::SLOT_BYTES;
     const uint8_t *k_pr = d_pr, *k_in = d_in;
     uint8_t*       k_st = d_st;
+    // the staging area and the key's small buffers are shared by every caller of this context: one latency verification at
+    // a time (two threads could otherwise read each other's flags), from the staging copy to the read-back
+    std::unique_lock<std::mutex> staging_lock(ctx->verify_mu, std::defer_lock);
+    if (n <= k16_vk::SMALL_N) staging_lock.lock();
     if (mapped) {
         memcpy(hp, h_proofs, (size_t)n * 256);
         if (in_bytes) memcpy(hp + 16384, h_inputs, in_bytes);
@@ -810,7 +816,10 @@ extern "C" int k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_pr
         }
         if (generic) {
             int rc = verify_coop(ctx, vk, h_proofs, h_inputs, n, h_ok, nullptr);
-            if (rc != 1) return rc; // K16_OK or an error; 1 = a proof was left undecided: general path
+            if (rc == K16_OK) return rc;
+            // 1 = a proof was left undecided; an error (a launch that did not fit after all, an allocation): either way the
+            // general path below decides the batch -- the cooperative path is an accelerator, never the only way
+            if (rc != 1) (void)hipGetLastError();
         }
     }
     DevBufs     tmp;

@@ -272,6 +272,11 @@ inline void coop_const_table(const PairConsts& K, const Fp12& eab, const std::ve
 #ifndef COOP_MAX_COEF
 #define COOP_MAX_COEF (1 << 12)
 #endif
+// what k_verify_coop's linear step is built around (verify.hip): a bias of 2^15 p under coefficients of at most COOP_MAX_COEF
+// times values below 5p, int16 coefficients, a 6-bit term count, whole trips of a power-of-two number of terms
+static_assert(COOP_MAX_COEF * 5 < (1 << 15), "linear step: the 2^15 p bias must cover the negative part of a combination");
+static_assert(COOP_MAX_TERMS < 64, "linear step: 6-bit term count");
+static_assert((COOP_TRIP_TERMS & (COOP_TRIP_TERMS - 1)) == 0, "linear step: terms per trip must be a power of two");
 // Builds the program.  Depends only on the curve constants' zero / one pattern (K), not on a key.
 inline void coop_build_program(const PairConsts& K, CoopProgram* P)
 {

@@ -215,3 +215,37 @@ def test_classified_msm_witness_2p20_vs_oracle(ctx, group):
     ctx.classes_destroy(cls)
     for d in (d_b, d_p, d_s, mask):
         d.free()
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_bucket_sort_leaves_out_zero_rows_through_the_mask(ctx, group):
+    """k16_msm_set_zero_row_mask: the ordinary (bucket) MSM with the table's (0,0) rows left out of its sort gives the same
+    sum (curve.cpp:185-250: adding (0,0) returns the other operand); the mask covers ONE enqueue."""
+    n = 1 << 17 if group == 0 else 1 << 15
+    s = np_scalars(19 + group, n, "witness")
+    d_b = ctx.synth_points(group, 3, n)
+    bases = d_b.download(np.uint8, (n, 64 if group == 0 else 128)).copy()
+    rs = np.random.RandomState(4)
+    bases[rs.rand(n) < 0.5] = 0
+    bases[:3] = 0
+    d_b.upload(bases)
+    d_p = ctx.bases_prepare(group, d_b, n)
+    mask = ctx.zero_row_mask(group, d_p, n)
+    m = mask.download(np.uint64)[: (n + 63) // 64]
+    bits = np.unpackbits(m.view(np.uint8), bitorder="little")[:n].astype(bool)
+    assert np.array_equal(bits, ~bases.any(axis=1))
+    d_s = ctx.to_device(s)
+    _, want = ol.msm(group, bases, s, nthreads=8)
+    ctx.set_window_bits(13)
+    try:
+        ctx.msm_set_zero_row_mask(mask)
+        ctx.msm_enqueue_prepared(group, d_p, d_s, n)
+        _, got = ctx.msm_finish(group)
+        assert got == want
+        ctx.msm_enqueue_prepared(group, d_p, d_s, n)      # the mask was consumed: a plain sort again
+        _, got = ctx.msm_finish(group)
+        assert got == want
+    finally:
+        ctx.set_window_bits(0)
+    for d in (d_b, d_p, d_s, mask):
+        d.free()

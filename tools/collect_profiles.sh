@@ -1,8 +1,8 @@
 #!/bin/bash
-# Collects every measurement DESIGN.md / README quote for this round on the GPU box into gpurun_out/r03/ (copy the
-# summaries into profiles/r03/ afterwards).  Run through gpurun from the repository root.
+# Collects every measurement DESIGN.md / README quote for this round on the GPU box into gpurun_out/r04/ (copy the
+# summaries into profiles/r04/ afterwards).  Run through gpurun from the repository root.
 set -u
-O=gpurun_out/r03
+O=gpurun_out/${ROUND:-r04}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # 1. the driver's command, plain
@@ -11,8 +11,8 @@ python3 bench.py --steps 100 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_
 # 2. the same command under rocprofv3 --kernel-trace --stats (kernel averages the roofline must agree with)
 K16_BENCH_NO_COLD=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --proofs 0 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 # 3. PMC traffic, one counter per pass, one MSM at a time
-K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
-K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
+K16_BENCH_NO_COLD=1 K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
+K16_BENCH_NO_COLD=1 K16_BENCH_DEPTH=1 K16_BENCH_PREWARM=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --proofs 0 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
 # 4. instruction-rate microbenchmarks (the multiply peak the ALU roofline uses)
 ./tools/ubench > $O/ubench_instruction_rates.log 2>&1
 # 5. proofs: latency / throughput / facade, and the kernel statistics of a proof
