@@ -140,10 +140,14 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     extern __shared__ uint4 ntt_lds[];
-    Fr9*           tile  = reinterpret_cast<Fr9*>(ntt_lds);
+    uint32_t*      lds32 = reinterpret_cast<uint32_t*>(ntt_lds);
+    // element e of the tile: nine dwords; the TAIL variant (which reads the tile mid-major: a stride of 9 T dwords between
+    // adjacent lanes) skips one dword after every 64 elements, which spreads ANY power-of-two element stride over all 64
+    // banks (round 3 padded every tile row by a whole element: 50 % more LDS at T = 2)
+    auto at = [&](uint32_t e) -> Fr9& { return *reinterpret_cast<Fr9*>(lds32 + e * 9u + (TAIL ? (e >> 6) : 0u)); };
     Fr* __restrict__ a   = pp.src[blockIdx.y];
     const uint32_t T     = 1u << TL;
-    const uint32_t RS    = (TAIL && TL) ? T + 1 : T; // tile row stride in elements
+    const uint32_t RS    = T; // tile row stride in elements
     const uint32_t telem = T << K;
     const uint32_t lo_tiles = (1u << s0) >> TL;
     const uint32_t hi    = blockIdx.x / lo_tiles;
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
     for (uint32_t e = threadIdx.x; e < telem; e += blockDim.x) {
         const uint32_t mid = e >> TL, tl = e & (T - 1);
         const Fr*      src = &a[base + ((size_t)mid << s0) + tl];
-        tile[mid * RS + tl] = CONV_IN ? fr9_from_fr(ld_fr(src)) : ld_r9(src);
+        at(mid * RS + tl) = CONV_IN ? fr9_from_fr(ld_fr(src)) : ld_r9(src);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
@@ -170,11 +174,11 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
             const uint32_t ml = mm & (half - 1), mh = mm >> (t - 1);
             const uint32_t m0 = (mh << t) + ml, m1 = m0 + half;
             const size_t   j  = ((size_t)ml << s0) + lo0 + tl;
-            Fr9            x1 = tile[m1 * RS + tl];
-            Fr9            u  = tile[m0 * RS + tl];
+            Fr9            x1 = at(m1 * RS + tl);
+            Fr9            u  = at(m0 * RS + tl);
             Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_tw9(roots9, j << (S - s0 - t)), x1); // s0 == 0: the twiddle is 1
-            tile[m0 * RS + tl] = fadd9(u, tt);
-            tile[m1 * RS + tl] = fsub9_t<Fr9C, 2>(u, tt);
+            at(m0 * RS + tl) = fadd9(u, tt);
+            at(m1 * RS + tl) = fsub9_t<Fr9C, 2>(u, tt);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
             const uint32_t i0 = m0 * RS + tl, dh = h * RS;
             const size_t   ja = ((size_t)ml << s0) + lo0 + tl;         // twiddle index of stage t, and of (m0, m0+2h) in t+1
             const size_t   jb = ((size_t)(ml + h) << s0) + lo0 + tl;   // (m0+h, m0+3h) in stage t+1
-            Fr9            x0 = tile[i0], x1 = tile[i0 + dh], x2 = tile[i0 + 2 * dh], x3 = tile[i0 + 3 * dh];
+            Fr9            x0 = at(i0), x1 = at(i0 + dh), x2 = at(i0 + 2 * dh), x3 = at(i0 + 3 * dh);
             const bool     unit = (s0 == 0 && t == 1); // first two stages of a transform: ja = 0, the twiddles are 1
             Fr9            p1, p3;
             if (unit) {
@@ -221,13 +225,13 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
             }
             Fr9 q2 = unit ? a2 : frmul9(ld_tw9(roots9, ja << (S - s0 - t - 1)), a2);
             Fr9 q3 = frmul9(ld_tw9(roots9, jb << (S - s0 - t - 1)), a3);
-            tile[i0]          = fadd9(a0, q2);
+            at(i0)          = fadd9(a0, q2);
             // unit: q2 = a2 = x2 + x3 is not fresh from a multiplication -- up to 4r, so the offset must be 4r (with 2r the
             // difference goes negative when x2, x3 >= r and x0 + x1 is small: about once per 10^3 proofs of 2^21 with
             // inputs < 1.006 r, every proof with inputs < 1.07 r)
-            tile[i0 + 2 * dh] = unit ? fsub9_t<Fr9C, 4>(a0, q2) : fsub9_t<Fr9C, 2>(a0, q2);
-            tile[i0 + dh]     = fadd9(a1, q3);
-            tile[i0 + 3 * dh] = fsub9_t<Fr9C, 2>(a1, q3);
+            at(i0 + 2 * dh) = unit ? fsub9_t<Fr9C, 4>(a0, q2) : fsub9_t<Fr9C, 2>(a0, q2);
+            at(i0 + dh)     = fadd9(a1, q3);
+            at(i0 + 3 * dh) = fsub9_t<Fr9C, 2>(a1, q3);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
@@ -240,7 +244,7 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
             const uint32_t f   = (uint32_t)base + (mid << s0) + tl;
             const uint32_t i   = (0u - f) & nm1;                       // (n - f) mod n
             const uint32_t to  = logn ? (__brev(i) >> (32 - logn)) : 0u;
-            st_r9(&d[to], frmul9(tile[mid * RS + tl], ld_r9(&shift9[i]))); // 32 * 2 <= 128: < 2r
+            st_r9(&d[to], frmul9(at(mid * RS + tl), ld_r9(&shift9[i]))); // 32 * 2 <= 128: < 2r
         }
         return;
     }
@@ -248,9 +252,9 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
         const uint32_t mid = e >> TL, tl = e & (T - 1);
         Fr*            dst = &a[base + ((size_t)mid << s0) + tl];
         if (CONV_OUT)
-            st_fr(dst, fr9_to_fr(tile[mid * RS + tl]));             // multiply by 2^256 / 2^261: any bound <= 64r is fine
+            st_fr(dst, fr9_to_fr(at(mid * RS + tl)));             // multiply by 2^256 / 2^261: any bound <= 64r is fine
         else
-            st_r9(dst, fred9_t<Fr9C>(tile[mid * RS + tl]));         // < r (1 + 2^-17): fits the 32-byte packed form
+            st_r9(dst, fred9_t<Fr9C>(at(mid * RS + tl)));         // < r (1 + 2^-17): fits the 32-byte packed form
     }
 }
 // shift9[i] = 2^-logn * g^i, g the primitive 2^(logn+1)-th root: the factor between the inverse and the coset-forward transform
@@ -360,13 +364,14 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
     }
     const uint64_t n  = 1ull << logn;
     uint32_t       s0 = 0;
-    // Tile size.  1024 elements (36 KB of LDS, four workgroups per CU): 21 stages are three passes (10 + 6 + 5).  2048
-    // elements (72 KB, two workgroups of 512 threads per CU): two passes (11 + 10) -- one load / store round trip and one
-    // fill-and-drain of the chip less per transform, at the price of 64-byte runs in the second pass (T = 2).  Measured in
-    // a proof (three polynomials per launch, 2^21): forward 455 + 588 us against 610 + 349 + 300; the TAIL pass of the
-    // inverse transforms needs a padded tile (110 KB, one workgroup per CU) and loses (1156 us against 393 + 450), so the
-    // inverse transforms keep the small tile (k16_ntt_coset_chain).
-    if (tail_dst) tile_log = 10;
+    // Tile size.  1024 elements (36 KB of LDS, four workgroups per CU): 21 stages are three passes (10 + 6 + 5, 512-byte runs).
+    // K16_NTT_TILE_LOG=11: 2048 elements (72 KB, two workgroups of 512 threads per CU), two passes (11 + 10) -- one load /
+    // store round trip less per transform, but the second pass then moves 64-byte runs (T = 2: a tile is T x 2^10 elements
+    // whatever the layout between the passes).  Measured in a proof (three polynomials per launch, 2^21, round 4): forward
+    // 395 + 684 us against 610 + 349 + 300, the inverse with its TAIL store 372 + 1194 against 309 + 393 + 450; proof p50
+    // 6.03-6.18 (both), 5.85-6.06 (forward only) against 5.86-6.05 ms: no gain, so 1024 stays the default.
+    static const bool tail_small = getenv("K16_NTT_TAIL_SMALL") != nullptr;
+    if (tail_dst && tail_small) tile_log = 10;
     const uint32_t TLMAX = tile_log == 11 ? 1u : 4u;
     while (s0 < logn) {
         const uint32_t TL = s0 < TLMAX ? s0 : TLMAX;                    // T = min(2^s0, 16) lo values per tile
@@ -374,7 +379,8 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
         const bool     first = s0 == 0, last = s0 + K == logn;
         const bool     cin = !packed9 && first, cout = !packed9 && last, tail = tail_dst && last;
         const dim3     grid((unsigned)(n >> (K + TL)), (unsigned)count);
-        const size_t   lds = (size_t)(((tail && TL) ? (1u << TL) + 1 : (1u << TL)) << K) * sizeof(Fr9);
+        const size_t   telem = (size_t)1 << (TL + K);
+        const size_t   lds   = telem * sizeof(Fr9) + (tail ? (telem >> 6) * 4 + 16 : 0);
         const bool     big = lds > 48 * 1024; // 512 threads per workgroup, dynamic LDS above the default limit
 #define K16_NTT_LAUNCH(CI, CO, TA)                                                                                              \
     do {                                                                                                                        \
@@ -427,7 +433,7 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
             Fr* one[1] = {d_a};
             static const uint32_t pub_tile = [] {
                 const char* e = getenv("K16_NTT_TILE_LOG");
-                return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 11u;
+                return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 10u;
             }();
             ntt_passes(ctx, one, 1, logn, tab, packed9 != 0, nullptr, nullptr, st, logn >= 12 ? pub_tile : 10u);
         }
@@ -466,9 +472,9 @@ int k16_ntt_coset_chain(k16_ctx* ctx, k16::Fr* const* src, k16::Fr* const* dst, 
     k16_stat_scope ss(ctx, "ntt", st);
     static const uint32_t fwd_tile = [] {
         const char* e = getenv("K16_NTT_TILE_LOG");
-        return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 11u;
+        return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 10u;
     }();
-    ntt_passes(ctx, src, count, logn, tab, true, dst, shift9, st);
+    ntt_passes(ctx, src, count, logn, tab, true, dst, shift9, st, logn >= 12 ? fwd_tile : 10u);
     ntt_passes(ctx, dst, count, logn, tab, true, nullptr, nullptr, st, logn >= 12 ? fwd_tile : 10u);
     K16_HIP(ctx, hipGetLastError());
     return K16_OK;
