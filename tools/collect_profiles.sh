@@ -32,15 +32,23 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/k16_tl -- python3 tools/ben
 python3 tools/proof_timeline.py /tmp/k16_tl 2 > $O/proof_timeline.txt 2>> $O/proof_timeline.err
 python3 tools/fixed_base_timing.py 21 8 > $O/fixed_base_h_msm.log 2>&1
 python3 tools/ntt_timing.py 21 30 > $O/ntt_2p21.log 2>&1
-# 10. round 3: sort lab (per-kernel averages of the product's bucket sort), verifier trace, PMC write traffic of the sort
+# 10. sort lab (per-kernel averages of the product's bucket sort), verifier trace, PMC write traffic of the sort
 tools/lab/sortlab 20 16 0 uniform 20 check > $O/sortlab_2p20_c16.log 2>&1
 tools/lab/sortlab 21 20 1 uniform 20 check > $O/sortlab_2p21_flat20.log 2>&1
-tools/lab/prof.sh r03s16 tools/lab/sortlab 20 16 0 uniform 20 > $O/sortlab_2p20_c16_kernels.txt 2>&1
-tools/lab/prof.sh r03sH tools/lab/sortlab 21 20 1 uniform 20 > $O/sortlab_2p21_flat20_kernels.txt 2>&1
-tools/lab/pmc.sh r03w16 WRITE_SIZE tools/lab/sortlab 20 16 0 uniform 3 > $O/sortlab_2p20_c16_WRITE_SIZE.txt 2>&1
+tools/lab/prof.sh r04s16 tools/lab/sortlab 20 16 0 uniform 20 > $O/sortlab_2p20_c16_kernels.txt 2>&1
+tools/lab/prof.sh r04sH tools/lab/sortlab 21 20 1 uniform 20 > $O/sortlab_2p21_flat20_kernels.txt 2>&1
+tools/lab/pmc.sh r04w16 WRITE_SIZE tools/lab/sortlab 20 16 0 uniform 3 > $O/sortlab_2p20_c16_WRITE_SIZE.txt 2>&1
+tools/lab/pmc.sh r04wH WRITE_SIZE tools/lab/sortlab 21 20 1 uniform 3 > $O/sortlab_2p21_flat20_WRITE_SIZE.txt 2>&1
+K16_NO_STAGED_SORT=1 tools/lab/sortlab 21 20 1 uniform 20 check > $O/sortlab_2p21_flat20_round3_sort.log 2>&1
+K16_NO_STAGED_SORT=1 tools/lab/sortlab 20 16 0 uniform 20 check > $O/sortlab_2p20_c16_round3_sort.log 2>&1
+# 10b. round 4: counters of the bucket accumulation over fixed-base tables of three sizes, of the NTT
+#      passes, VALU instructions per proof by kernel
+tools/lab/gather_counters.sh > $O/pmc_fixed_base_accumulate_tlb_l2.txt 2>&1
+tools/lab/ntt_counters.sh > $O/pmc_ntt_passes.txt 2>&1
+tools/lab/valu_per_proof.sh r04 > $O/valu_instructions_per_proof.txt 2>&1
 K16_VERIFY_COOP_TRACE=1 python3 tools/bench_verify.py > /dev/null 2> $O/verify_coop_trace.log   # (the trace build of the kernel is slower: not the numbers of record)
 ls -la $O
-# 11. summaries out of the raw rocprofv3 directories (what gets copied into profiles/r03/)
+# 11. summaries out of the raw rocprofv3 directories (what gets copied into profiles/r04/)
 cp "$(ls -S $(find $O/stats -name "*kernel_stats.csv") | head -1)" $O/bench_kernel_stats.csv   # (the largest: child processes write their own)
 cp "$(ls -S $(find $O/proof_stats -name "*kernel_stats.csv") | head -1)" $O/proof_keyless_shape_kernel_stats.csv
 python3 tools/pmc_kernel.py $O/pmc_fetch > $O/pmc_FETCH_SIZE_per_kernel.txt
