@@ -1003,29 +1003,35 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         ForcedC fc(ctx, wc);
         const uint64_t* skip_ac = (const uint64_t*)p->d_skip_ac;
         const uint64_t* skip_b  = p->b_sort ? (const uint64_t*)p->d_skip_b : skip_ac;
-        if (p->b_sort) {
-            // B2 (G2: the longest of the four) first, on lane 2, with a bucket sort of its own that leaves out the rows that
-            // are (0,0) in B1 and B2 -- half of them in a circuit whose wires mostly sit on one side of a constraint; as
-            // sorted entries they would cost a lane of every addition they sit beside.  It also starts without waiting for A's sort.
+        // K16_B2_FIRST=1 (lab): B2 leads on lane 2 and owns the SHARED sort, the G1 MSMs read it
+        static const bool b2_lead_env = getenv("K16_B2_FIRST") != nullptr;
+        const bool        b2_lead = b2_lead_env && !p->b_sort;
+        const int         own     = b2_lead ? 2 : 0; // lane whose sort A and C read
+        if (p->b_sort || b2_lead) {
+            // B2 (G2: the longest of the four) first, on lane 2.  K16_B_SORT: with a bucket sort of its own that leaves out the
+            // rows that are (0,0) in B1 and B2 -- half of them in a circuit whose wires mostly sit on one side of a constraint;
+            // as sorted entries they would cost a lane of every addition they sit beside.
             K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, 2), p->ev_w, 0));
             ctx->cur_lane  = 2;
             ctx->skip_next = skip_b;
             if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
         }
-        ctx->cur_lane  = 0;
-        ctx->skip_next = skip_ac;
+        ctx->cur_lane        = 0;
+        ctx->reuse_sort      = b2_lead;
+        ctx->reuse_sort_lane = own;
+        ctx->skip_next       = skip_ac;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars))) return rc;
         ctx->cur_lane        = 1;
         ctx->reuse_sort      = true; // C is indexed by wire (see k16_prover_create_mem): same scalars, same sort
-        ctx->reuse_sort_lane = 0;
+        ctx->reuse_sort_lane = own;
         ctx->skip_next       = skip_ac;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, p->n_vars))) return rc;
         ctx->cur_lane        = 0;
         ctx->reuse_sort      = true;
-        ctx->reuse_sort_lane = p->b_sort ? 2 : 0;
+        ctx->reuse_sort_lane = p->b_sort ? 2 : own;
         ctx->skip_next       = skip_b;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
-        if (!p->b_sort) {
+        if (!p->b_sort && !b2_lead) {
             // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
             ctx->cur_lane        = 2;
             ctx->reuse_sort      = true;
@@ -1080,7 +1086,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     };
     // results come back in enqueue order: classes A, B2, C, B1, H; bucket path B2, A, C, B1, H with a sort of its own for B,
     // A, C, B1, B2, H without
-    const bool b2_first = !p->cls && p->b_sort;
+    const bool b2_first = !p->cls && (p->b_sort || getenv("K16_B2_FIRST") != nullptr);
     if (b2_first && (rc = finish_b2())) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_a, nullptr))) return rc;
     ht("A finished");
