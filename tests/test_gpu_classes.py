@@ -2,6 +2,8 @@
 "Scalar-class MSM" part of csrc/msm_kernels.inc) through the C ABI against the CPU oracle's multiexp on the SAME bases and
 scalars.  It replaces what the reference's zero-digit skip (multiexp.cpp:59-65) does for the four witness MSMs of
 groth16.cpp:88-112, so the cases are the witness's: zeros, ones, bytes, field elements, class boundaries, (0,0) rows."""
+import os
+
 import numpy as np
 import pytest
 
@@ -249,3 +251,26 @@ def test_bucket_sort_leaves_out_zero_rows_through_the_mask(ctx, group):
         ctx.set_window_bits(0)
     for d in (d_b, d_p, d_s, mask):
         d.free()
+
+
+@pytest.mark.parametrize("mode", ["classes", "b_sort"])
+def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, monkeypatch, mode):
+    """BASELINE config 3 at its stated size (nVars 1,343,588, N = 2^21, B1 / B2 half (0,0)) with the witness MSMs taking
+    the two paths that are off by default -- scalar classes (K16_CLASSES=1) and a bucket sort of B's own without its (0,0)
+    rows (K16_B_SORT=1): proof JSON byte-equal to the CPU oracle's (RS/groth16.cpp:41-360), for two witnesses on one
+    prover."""
+    import bench
+    import k16
+    monkeypatch.setenv("K16_CLASSES" if mode == "classes" else "K16_B_SORT", "1")
+    n_vars, N, n_coefs = bench.KEYLESS["n_vars"], bench.KEYLESS["domain"], bench.KEYLESS["n_coefs"]
+    zk = str(tmp_path / "keyless_shape.zkey")
+    wt = str(tmp_path / "keyless_shape.wtns")
+    with open(zk, "wb") as f:
+        f.write(bench.synth_zkey_bytes(ctx, k16, n_vars, 1, N, n_coefs))
+    r, s = pm.limbs(pm.SplitMix64(277).below(pm.R)), pm.limbs(pm.SplitMix64(278).below(pm.R))
+    p = k16.Prover(ctx, zk)          # reads the switches when the key is loaded
+    for seed in (100, 103):
+        w = bench.synth_witness(n_vars, seed)
+        bench.write_wtns(wt, w)
+        assert p.prove_mem(w, r, s) == ol.prove_files(zk, wt, r, s, nthreads=os.cpu_count() or 8)
+    p.close()
