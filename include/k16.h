@@ -235,6 +235,14 @@ int  k16_prover_prove_file_timed(k16_prover* p, const char* wtns_path, const uin
 /* witness already in memory: n_vars x 32 B standard form (the payload of wtns section 2) */
 int  k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_std,
                           const uint8_t* s_std, char* out_json, size_t cap, float* device_ms);
+/* The drop-in FullProver (include/k16_fullprover.hpp) with the witness in memory: `fullprover` points to a FullProver object
+ * (the one the Rust crate holds; its pool of provers -- K16_DEVICES -- serves concurrent callers), wtns_values is the payload
+ * of the .wtns file's section 2.  FullProver::prove(path) maps and parses a 43 MB file inside every call; a service that
+ * keeps several GPUs busy binds this instead.  Returns the JSON's length, or K16_ERR_NO_DEVICE (the reference's
+ * PROVER_NOT_READY: not constructed, or every device retired), K16_ERR_HIP (device fault: the slot was rebuilt, retry),
+ * K16_ERR_FORMAT / K16_ERR_ARG / K16_ERR_BUFFER / K16_ERR_NOMEM.  prover_time_ms: wall time of the call (may be NULL). */
+int  k16_fullprover_prove_mem(const void* fullprover, const void* wtns_values, uint64_t n_values, char* out_json, size_t cap,
+                              int* prover_time_ms);
 /* debugging / parity: H scalars of the last proof (domain_size x 32 B, standard form) */
 int  k16_prover_last_h(k16_prover* p, void* h_out);
 /* status of the discarded warm-up proof k16_prover_create runs (K16_OK, or the error it ended with: a prover whose device

@@ -219,6 +219,43 @@ FullProver::~FullProver()
     if (impl) delete impl;
 }
 
+// The pool with the witness ALREADY IN MEMORY (include/k16.h k16_fullprover_prove_mem): what a service that keeps several
+// GPUs busy binds instead of prove(path), which maps and parses a 43 MB .wtns file inside every call.  Same slot lease,
+// same quarantine of a slot after a device fault; the status is the C ABI's instead of a ProverResponse.
+extern "C" int k16_fullprover_prove_mem(const void* fullprover, const void* wtns_values, uint64_t n_values, char* out_json,
+                                        size_t cap, int* prover_time_ms)
+{
+    try {
+        // the object's two (private) fields, in the order the header -- the reference's -- declares them; bindgen sees the same
+        struct Fields {
+            FullProverImpl* impl;
+            FullProverState state;
+        } f;
+        static_assert(sizeof(Fields) == sizeof(FullProver), "FullProver layout");
+        if (prover_time_ms) *prover_time_ms = 0;
+        if (!fullprover || !wtns_values || !out_json) return K16_ERR_ARG;
+        memcpy(&f, fullprover, sizeof f);
+        const Fields* fp = &f;
+        if (fp->state != FullProverState::OK || !fp->impl) return K16_ERR_NO_DEVICE; // = PROVER_NOT_READY
+        int        rc;
+        const auto t0 = std::chrono::steady_clock::now();
+        {
+            FullProverImpl::Lease lease(fp->impl);
+            FullProverImpl::Slot* slot = lease.slot;
+            if (!slot) return K16_ERR_NO_DEVICE; // every device of the pool has been retired
+            rc = k16_prover_prove_mem(slot->prover, wtns_values, n_values, nullptr, nullptr, out_json, cap, nullptr);
+            if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) fp->impl->quarantine(slot);
+        }
+        if (prover_time_ms)
+            *prover_time_ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return K16_ERR_NOMEM;
+    } catch (...) {
+        return K16_ERR_HIP;
+    }
+}
+
 ProverResponse FullProver::prove(const char* input) const
 {
     if (state != FullProverState::OK || !impl) return ProverResponse(ProverError::PROVER_NOT_READY);

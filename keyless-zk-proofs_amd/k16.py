@@ -38,7 +38,7 @@ SYMBOLS = [
     "k16_msm_zero_row_mask", "k16_msm_set_zero_row_mask", "k16_scalar_classes_create", "k16_scalar_classes_destroy", "k16_scalar_classes_build", "k16_scalar_classes_counts", "k16_msm_enqueue_classified",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
-    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
+    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_fullprover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
     "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_verify_coop_gt", "k16_pairing_vec",
 ]
 

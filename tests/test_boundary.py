@@ -142,6 +142,38 @@ def test_fullprover_pool_concurrent_callers(tmp_path, toy_paths):
 
 
 @pytest.mark.gpu
+def test_fullprover_pool_with_the_witness_in_memory(tmp_path, toy_paths):
+    """k16_fullprover_prove_mem: the facade's pool (K16_DEVICES=0,0,0), four caller threads, the witness handed over in
+    memory instead of as a file path -- what a multi-GPU service binds.  Every proof verifies
+    (prover_handler.rs:279-290); a prover that failed to construct answers PROVER_NOT_READY; a witness shorter than the
+    circuit is the caller's fault."""
+    import json
+    import bn254_pairing as bp
+    zkey, wtns, vk = toy_paths
+    exe = build_harness(tmp_path)
+    env = dict(os.environ, K16_DEVICES="0,0,0", K16_HARNESS_MEM="1")
+    out = subprocess.run([exe, zkey, wtns, "2", "4"], capture_output=True, text=True, timeout=300, env=env)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr
+    proofs = [lines[2 + 2 * k] for k in range(8)]
+    for k in range(8):
+        assert lines[1 + 2 * k].startswith("type=0 error=0 ms="), lines
+    assert len(set(proofs)) == 8
+    for js in proofs[:4]:
+        assert json.loads(js)["protocol"] == "groth16"
+        assert bp.verify_json(vk, js, [2])
+    missing = subprocess.run([exe, str(tmp_path / "nope.zkey"), wtns], capture_output=True, text=True, timeout=120, env=env)
+    assert missing.stdout.splitlines()[0] == "state=1"
+    assert missing.stdout.splitlines()[1].startswith("type=1 error=1")      # PROVER_NOT_READY
+    w = open(wtns, "rb").read()
+    short = tmp_path / "short.wtns"                                            # section 2 cut to two values
+    i = w.index(b"\x02\x00\x00\x00", 12 + 12 + 40)
+    short.write_bytes(w[:i] + b"\x02\x00\x00\x00" + (64).to_bytes(8, "little") + w[i + 12:i + 12 + 64])
+    bad = subprocess.run([exe, zkey, str(short)], capture_output=True, text=True, timeout=120, env=env)
+    assert bad.stdout.splitlines()[1].startswith("type=1 error=2"), bad.stdout   # INVALID_INPUT
+
+
+@pytest.mark.gpu
 def test_fullprover_device_fault_is_not_the_callers_fault(tmp_path, toy_paths):
     """A HIP failure inside prove() (injected: K16_FAULT_INJECT) is reported as PROVER_NOT_READY -- the class the service
     retries -- not INVALID_INPUT, the slot is rebuilt in a fresh context before it is handed out again, and the proofs
