@@ -232,8 +232,9 @@ def write_wtns(path, w):
         f.write(b"wtns" + struct.pack("<II", 2, 2) + _section(1, sec1) + _section(2, w.tobytes()))
 
 
-def facade_leg(zpath, wpath, proofs):
-    """The file-based drop-in boundary: FullProver(zkey).prove(wtns_path) in a C++ process (tests/cpp/fullprover_harness.cpp,
+def facade_leg(zpath, wpath, proofs, mem=False):
+    """mem=True: the same FullProver object through k16_fullprover_prove_mem (the witness handed over in memory).
+    The file-based drop-in boundary: FullProver(zkey).prove(wtns_path) in a C++ process (tests/cpp/fullprover_harness.cpp,
     what the Rust crate does through bindgen), timed by the harness around its prove() loop."""
     pkg = os.path.join(ROOT, "keyless-zk-proofs_amd")
     exe = os.path.join(pkg, "fullprover_harness")
@@ -242,7 +243,8 @@ def facade_leg(zpath, wpath, proofs):
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", "fullprover_harness.cpp"), "-L", pkg, "-lk16",
                                "-Wl,-rpath," + pkg, "-pthread", "-o", exe])
-    out = subprocess.run([exe, zpath, wpath, str(proofs + 1)], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, K16_HARNESS_MEM="1") if mem else None
+    out = subprocess.run([exe, zpath, wpath, str(proofs + 1)], capture_output=True, text=True, timeout=600, env=env)
     lines = out.stdout.splitlines()
     ms = [int(l.split("ms=")[1]) for l in lines if l.startswith("type=0 error=0")]
     tot = [l for l in lines if l.startswith("elapsed_ms=")]
@@ -251,6 +253,9 @@ def facade_leg(zpath, wpath, proofs):
     # the first prove of a fresh process allocates the MSM workspaces: reported, not averaged in
     elapsed = float(tot[0].split()[0].split("=")[1])
     steady = (elapsed - ms[0]) if elapsed > ms[0] else elapsed
+    if mem:
+        return {"proofs_per_s": proofs / (steady * 1e-3), "proofs": proofs,
+                "note": "k16_fullprover_prove_mem on the same FullProver object: the witness values in memory, no file"}
     return {"proofs_per_s": proofs / (steady * 1e-3), "prover_time_ms_p50": float(np.median(ms[1:])),
             "first_prove_ms": ms[0], "proofs": proofs,
             "note": "FullProver(zkey).prove(path): mmap + parse of the 43 MB .wtns file inside every call; prover_time is "
@@ -409,6 +414,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         if world == 1:
             try:
                 out["facade"] = facade_leg(zpath, wpath, max(4, proofs // 2))
+                out["facade_mem"] = facade_leg(zpath, wpath, max(4, proofs // 2), mem=True)
             except Exception as e:
                 out["facade"] = {"error": repr(e)}
         if check_with_oracle:
