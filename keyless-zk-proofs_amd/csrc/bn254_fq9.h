@@ -125,6 +125,38 @@ K16_HD Fq9 fmul9_t(const Fq9& a, const Fq9& b)
 }
 K16_HD Fq9 fmul9(const Fq9& a, const Fq9& b) { return fmul9_t<Fq9C>(a, b); }
 
+// a * v / R' for a single-limb v < 2^29: fmul9_t with b = {v, 0, ..., 0} -- the same integer product, hence the same limbs,
+// for 9 + 81 multiply-adds instead of 162 (the SpMV's witness values are below 256 for 98 % of the wires).
+template <class C>
+K16_HD Fq9 fmul9_small_t(const Fq9& a, uint32_t v)
+{
+    uint32_t m[9];
+    Fq9      r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc2 = 0;
+        if (k < 9) acc += (uint64_t)a.l[k] * v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            if (k >= 9 || i < k) acc2 += (uint64_t)m[i] * C::P[j];
+        }
+        acc += acc2;
+        if (k < 9) {
+            m[k] = ((uint32_t)acc * C::NP) & C::MASK;
+            acc += (uint64_t)m[k] * C::P[0];
+            acc >>= 29;
+        } else {
+            r.l[k - 9] = (uint32_t)acc & C::MASK;
+            acc >>= 29;
+        }
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
 // a^2 / R': the 36 off-diagonal products are formed once against the doubled limbs (2*a_i < 2^30), so a
 // squaring is 45 + 81 multiply-adds instead of 162.  Column bound: 4 * 2^59 + 2^58 + 9 * 2^58 < 2^63.
 template <class C>

@@ -149,16 +149,28 @@ __global__ void __launch_bounds__(256) k_spmv(const SpmvSlice* __restrict__ slic
                                               const uint32_t* __restrict__ row_of, const SpmvLong* __restrict__ longs,
                                               uint32_t n_long, const uint32_t* __restrict__ wire,
                                               const Fr* __restrict__ coef9, const Fr* __restrict__ wtns,
-                                              Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N, uint32_t logN)
+                                              Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N, uint32_t logN,
+                                              const uint16_t* __restrict__ n16)
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     Fr9            acc = fq9_zero();
+    // n16 (round 4): one 16-bit word per wire -- the value when it is below 256, bit 15 when it is not.  98 % of a circuit's
+    // wires are bits and bytes: the walk's dependent gather then hits a 2.7 MB array (L2) instead of the 43 MB witness, and
+    // the product is a single-limb multiplication; only the wide wires load their 32 bytes.  Same integers, same limbs.
+    auto term = [&](uint32_t e) -> Fr9 {
+        const uint32_t wi = wire[e];
+        if (n16) {
+            const uint32_t c = n16[wi];
+            if (!(c & 0x8000u)) return fmul9_small_t<Fr9C>(ld_r9(&coef9[e]), c);
+        }
+        return frmul9(ld_r9(&wtns[wi]), ld_r9(&coef9[e]));
+    };
     if (w < n_slices) {
         const SpmvSlice sl = slices[w];
         for (uint32_t k = 0; k < sl.len; k++) {
             const uint32_t e = sl.off + (k << 6) + lane; // padding entries: wire 0, coefficient 0
-            acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[e]]), ld_r9(&coef9[e])));
+            acc = fradd9(acc, term(e));
         }
         const uint32_t row = row_of[(w << 6) + lane];
         if (row != 0xffffffffu) spmv_store(a, b, row, N, logN, acc);
@@ -168,7 +180,7 @@ __global__ void __launch_bounds__(256) k_spmv(const SpmvSlice* __restrict__ slic
     const SpmvLong L = longs[w - n_slices];
     for (uint32_t k = lane; k < L.len; k += 64) {
         const uint32_t e = L.off + k;
-        acc = fradd9(acc, frmul9(ld_r9(&wtns[wire[e]]), ld_r9(&coef9[e])));
+        acc = fradd9(acc, term(e));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -200,13 +212,24 @@ __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr
 // bytes): 43 MB for the Keyless circuit, 0.78 ms of PCIe time during which the GPU has nothing to do.  The host (a few
 // threads, witness_pack below) splits it into one byte per wire + a list of the wide values (2.3 MB); this kernel rebuilds
 // the n x 32-byte array in HBM, reading both straight from pinned, device-mapped host memory.  Same bytes as the plain copy.
-__global__ void __launch_bounds__(256) k_wtns_expand_narrow(const uint8_t* __restrict__ narrow, Fr* __restrict__ out, uint32_t n)
+__global__ void __launch_bounds__(256) k_wtns_expand_narrow(const uint8_t* __restrict__ narrow, Fr* __restrict__ out, uint32_t n,
+                                                            uint16_t* __restrict__ n16)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint4* d = reinterpret_cast<uint4*>(&out[i]);
     d[0]     = make_uint4((uint32_t)narrow[i], 0u, 0u, 0u);
     d[1]     = make_uint4(0u, 0u, 0u, 0u);
+    n16[i]   = narrow[i]; // (k_wtns_expand_wide, behind this kernel on the stream, flags the wide wires)
+}
+// plain-copy path: the same 16-bit array from the full witness
+__global__ void __launch_bounds__(256) k_wtns_n16(const uint4* __restrict__ wtns, uint32_t n, uint16_t* __restrict__ n16)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 lo = wtns[2 * (size_t)i], hi = wtns[2 * (size_t)i + 1];
+    const bool  wide = ((lo.x >> 8) | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) != 0;
+    n16[i] = wide ? (uint16_t)0x8000u : (uint16_t)lo.x;
 }
 struct WideLists {
     const uint32_t* idx[32];
@@ -214,14 +237,16 @@ struct WideLists {
     uint32_t        count[32];
     uint32_t        n_lists;
 };
-__global__ void __launch_bounds__(256) k_wtns_expand_wide(WideLists L, Fr* __restrict__ out)
+__global__ void __launch_bounds__(256) k_wtns_expand_wide(WideLists L, Fr* __restrict__ out, uint16_t* __restrict__ n16)
 {
     const uint32_t t = blockIdx.y;
     if (t >= L.n_lists) return;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < L.count[t]; j += gridDim.x * blockDim.x) {
-        uint4* d = reinterpret_cast<uint4*>(&out[L.idx[t][j]]);
+        const uint32_t i = L.idx[t][j];
+        uint4*         d = reinterpret_cast<uint4*>(&out[i]);
         d[0]     = L.val[t][2 * j];
         d[1]     = L.val[t][2 * j + 1];
+        n16[i]   = (uint16_t)0x8000u;
     }
 }
 
@@ -311,6 +336,7 @@ struct k16_prover {
     uint32_t   n_slices = 0, n_long = 0;
     // per-proof buffers
     Fr *d_wtns = nullptr, *d_a = nullptr, *d_b = nullptr, *d_c = nullptr, *d_t[3] = {nullptr, nullptr, nullptr};
+    uint16_t* d_n16 = nullptr; // per wire: the value when below 256, bit 15 otherwise (k_spmv)
     Fr* d_shift9 = nullptr; // 2^-k * g^i: between the inverse and the coset-forward transform (k16_ntt_build_coset_shift)
     k16_ntt_table* ntt = nullptr;
     hipStream_t    st2 = nullptr;          // polynomial chain (SpMV, NTTs) runs beside the witness MSMs
@@ -448,7 +474,7 @@ static void prover_free(k16_prover* p)
 {
     if (!p) return;
     void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_Htab, p->d_B2, p->d_slices, p->d_longs, p->d_rowof, p->d_wire, p->d_coef,
-                    p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t[0], p->d_t[1], p->d_t[2], p->d_shift9};
+                    p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t[0], p->d_t[1], p->d_t[2], p->d_shift9, p->d_n16};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (p->st2) (void)hipStreamDestroy(p->st2);
@@ -601,6 +627,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_wire, wire.size() * 4), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_coef, vals.size()), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_wtns, nv * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_n16, nv * 2 + 64), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_a, (size_t)N * 32), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_b, (size_t)N * 32), p);
     K16_HIP_P(ctx, hipMalloc((void**)&p->d_c, (size_t)N * 32), p);
@@ -906,12 +933,13 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
             L.count[t] = w->count[t];
             most       = std::max(most, w->count[t]);
         }
-        hipLaunchKernelGGL(k_wtns_expand_narrow, dim3((p->n_vars + 255) / 256), dim3(256), 0, st, w->d_narrow, p->d_wtns, p->n_vars);
+        hipLaunchKernelGGL(k_wtns_expand_narrow, dim3((p->n_vars + 255) / 256), dim3(256), 0, st, w->d_narrow, p->d_wtns, p->n_vars, p->d_n16);
         if (most)
-            hipLaunchKernelGGL(k_wtns_expand_wide, dim3(std::min<uint32_t>((most + 255) / 256, 64), w->n_threads), dim3(256), 0, st, L, p->d_wtns);
+            hipLaunchKernelGGL(k_wtns_expand_wide, dim3(std::min<uint32_t>((most + 255) / 256, 64), w->n_threads), dim3(256), 0, st, L, p->d_wtns, p->d_n16);
         K16_HIP(ctx, hipGetLastError());
     } else {
         K16_HIP(ctx, hipMemcpyAsync(p->d_wtns, h_wtns, (size_t)p->n_vars * 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_wtns_n16, dim3((p->n_vars + 255) / 256), dim3(256), 0, st, (const uint4*)p->d_wtns, p->n_vars, p->d_n16);
         if (p->cls) n_wide = (int64_t)count_wide_host(ctx, h_wtns, p->n_vars);
     }
     if (p->cls) {
@@ -927,11 +955,13 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     K16_HIP(ctx, hipEventRecord(p->ev_w, st));
     K16_HIP(ctx, hipStreamWaitEvent(s2, p->ev_w, 0));
     const unsigned gN = (N + 255) / 256;
+    static const bool spmv_n16 = getenv("K16_SPMV_FULL") == nullptr;
     {
         const uint64_t waves = (uint64_t)p->n_slices + p->n_long;
         if (waves)
             hipLaunchKernelGGL(k_spmv, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s2, p->d_slices, p->n_slices, p->d_rowof,
-                               p->d_longs, p->n_long, p->d_wire, p->d_coef, p->d_wtns, p->d_a, p->d_b, N, p->logN);
+                               p->d_longs, p->n_long, p->d_wire, p->d_coef, p->d_wtns, p->d_a, p->d_b, N, p->logN,
+                               spmv_n16 ? (const uint16_t*)p->d_n16 : (const uint16_t*)nullptr);
     }
     hipLaunchKernelGGL(k_mul, dim3(gN), dim3(256), 0, s2, p->d_c, p->d_a, p->d_b, N); // elementwise: same permutation
     // a, b, c together: iNTT passes in place (input already bit-reversed; the last pass stores [tail, coset shift, bit
