@@ -425,7 +425,10 @@ static WitnessPacker* packer_create(k16_ctx* ctx, uint32_t n_vars)
 {
     k16_host_pool* pool = k16_ctx_pool(ctx);
     if (!pool || n_vars < (1u << 16)) return nullptr; // small circuits: the plain copy is a few microseconds
-    const unsigned T = std::min(pool->width(), 32u);
+    // 32 ranges whatever the pool's width (the expansion kernel takes up to 32 wide-value lists): with one range per thread a
+    // worker that the host's scheduler parks in the middle of its range holds the whole proof up (observed on a shared
+    // 256-CPU host: 1.4-6 ms instead of 0.25 for one proof in four); smaller ranges are handed to whoever is running
+    const unsigned T = 32u;
     WitnessPacker* w = new WitnessPacker();
     w->pool          = pool;
     w->n_threads     = T;
