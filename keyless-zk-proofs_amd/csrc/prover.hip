@@ -999,6 +999,8 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     };
     G1Xyzz pi_a, pib1, pi_c, pih;
     G2Xyzz pi_b;
+    static const bool probe_no_witness = getenv("K16_PROBE_NO_WITNESS") != nullptr; // lab: WRONG proofs, chain + H alone
+    const uint64_t    n_wit = probe_no_witness ? 1 : p->n_vars;
     unsigned wc = 13;
     if (const char* e = getenv("K16_WITNESS_C")) wc = (unsigned)atoi(e);
     if (p->n_vars < (1u << 17)) wc = 0; // small circuits: automatic
@@ -1047,30 +1049,30 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
             K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, 2), p->ev_w, 0));
             ctx->cur_lane  = 2;
             ctx->skip_next = skip_b;
-            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
+            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, n_wit))) return rc;
         }
         ctx->cur_lane        = 0;
         ctx->reuse_sort      = b2_lead;
         ctx->reuse_sort_lane = own;
         ctx->skip_next       = skip_ac;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, p->n_vars))) return rc;
+        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_A, p->d_wtns, n_wit))) return rc;
         ctx->cur_lane        = 1;
         ctx->reuse_sort      = true; // C is indexed by wire (see k16_prover_create_mem): same scalars, same sort
         ctx->reuse_sort_lane = own;
         ctx->skip_next       = skip_ac;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, p->n_vars))) return rc;
+        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, n_wit))) return rc;
         ctx->cur_lane        = 0;
         ctx->reuse_sort      = true;
         ctx->reuse_sort_lane = p->b_sort ? 2 : own;
         ctx->skip_next       = skip_b;
-        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, p->n_vars))) return rc;
+        if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, n_wit))) return rc;
         if (!p->b_sort && !b2_lead) {
             // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
             ctx->cur_lane        = 2;
             ctx->reuse_sort      = true;
             ctx->reuse_sort_lane = 0;
             ctx->skip_next       = skip_ac;
-            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, p->n_vars))) return rc;
+            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, n_wit))) return rc;
         }
     }
     ht("A C B1 B2 enqueued");
