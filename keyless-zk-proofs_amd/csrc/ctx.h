@@ -136,6 +136,8 @@ struct k16_ctx {
     const uint32_t* remap_next = nullptr;
     // zero-row mask of the NEXT bucket sort (consumed by it; an MSM that REUSES a sort must name the mask it was made with)
     const uint64_t* skip_next = nullptr;
+    // zero-row mask of the NEXT MSM's own table, applied in its accumulation (for a table that reuses another table's sort)
+    const uint64_t* acc_skip_next = nullptr;
     // K16_SERIALIZE_ACC=1 (bench.py sets it): a lane's bucket accumulation waits for the previous lane's.  Two of these
     // chip-filling kernels never overlap anyway (kernel traces: the second starts when the first ends), so nothing is
     // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence

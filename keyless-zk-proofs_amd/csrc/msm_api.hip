@@ -546,6 +546,7 @@ extern "C" int k16_msm_abort_all(k16_ctx* ctx)
     ctx->pend_reserved   = 0;
     ctx->remap_next      = nullptr;
     ctx->skip_next       = nullptr;
+    ctx->acc_skip_next   = nullptr;
     (void)hipSetDevice(ctx->device);
     for (auto& L : ctx->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);

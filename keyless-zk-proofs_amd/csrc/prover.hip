@@ -1061,10 +1061,14 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         ctx->reuse_sort_lane = own;
         ctx->skip_next       = skip_ac;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, n_wit))) return rc;
+        // B1 / B2 on a sort that contains their (0,0) rows: the accumulation steps over them (k_accumulate_skip)
+        static const bool acc_skip_on = getenv("K16_NO_ACC_SKIP") == nullptr;
+        const bool        b_skip = acc_skip_on && !p->b_sort && p->d_skip_ac;
         ctx->cur_lane        = 0;
         ctx->reuse_sort      = true;
         ctx->reuse_sort_lane = p->b_sort ? 2 : own;
         ctx->skip_next       = skip_b;
+        ctx->acc_skip_next   = b_skip ? (const uint64_t*)p->d_zmask[1] : nullptr;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, n_wit))) return rc;
         if (!p->b_sort && !b2_lead) {
             // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
@@ -1072,6 +1076,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
             ctx->reuse_sort      = true;
             ctx->reuse_sort_lane = 0;
             ctx->skip_next       = skip_ac;
+            ctx->acc_skip_next   = b_skip ? (const uint64_t*)p->d_zmask[2] : nullptr;
             if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, n_wit))) return rc;
         }
     }
