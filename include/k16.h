@@ -187,6 +187,13 @@ int  k16_msm_enqueue_classified(k16_ctx* ctx, int group, const void* d_prepared,
  * the AND of the masks of several tables that will share the sort) out of its bucket sort: (0,0) rows add nothing, but as
  * sorted entries they cost a lane of every addition they sit beside.  Covers one enqueue; n <= 2^24. */
 int  k16_msm_set_zero_row_mask(k16_ctx* ctx, const void* d_mask);
+/* The next k16_msm_enqueue_prepared on the current lane reads the bucket sort that `lane` has made of the SAME scalar
+ * array (same device pointer, n and window size; groth16.cpp:88-112: four MSMs over one witness) instead of sorting.
+ *   derive = 0  that lane's lists as they are (the zero-row mask named for this enqueue must be the one they were made with);
+ *   derive = 1  lists of the current lane's own, built from that lane's partition without the rows of this enqueue's
+ *               zero-row mask (a superset of the owner's): for a table with many (0,0) rows of its own.  Other lanes may
+ *               share the derived lists with derive = 0.  K16_ERR_ARG when that lane holds no matching sort. */
+int  k16_msm_sort_from_lane(k16_ctx* ctx, int lane, int derive);
 /* A context has K16_MSM_LANES independent MSM lanes (HIP stream + workspace).  The next k16_msm_enqueue* uses the
  * selected lane; MSMs on different lanes may overlap on the GPU (their inputs must already be complete: uploads
  * through k16_h2d are).  k16_msm_finish still returns results in enqueue order.  Default lane 0. */

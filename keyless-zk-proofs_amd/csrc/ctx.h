@@ -77,6 +77,7 @@ struct k16_ctx {
         uint64_t    sorted_n = 0;
         unsigned    sorted_c = 0;
         const uint64_t* sorted_skip = nullptr; // zero-row mask that sort was made with
+        bool        sorted_plain_partition = false; // ... and its partition (ws_lvl_d) can be read by a derived sort
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
@@ -138,6 +139,7 @@ struct k16_ctx {
     const uint64_t* skip_next = nullptr;
     // zero-row mask of the NEXT MSM's own table, applied in its accumulation (for a table that reuses another table's sort)
     const uint64_t* acc_skip_next = nullptr;
+    int             derive_lane   = -1; // next enqueue: bucket lists of its own from that lane's partition, minus skip_next's rows
     // K16_SERIALIZE_ACC=1 (bench.py sets it): a lane's bucket accumulation waits for the previous lane's.  Two of these
     // chip-filling kernels never overlap anyway (kernel traces: the second starts when the first ends), so nothing is
     // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence

@@ -212,6 +212,27 @@ extern "C" int k16_msm_set_zero_row_mask(k16_ctx* ctx, const void* d_mask)
     });
 }
 
+// The next k16_msm_enqueue_prepared reads the bucket sort another lane has made of the SAME scalar array (same device
+// pointer, n, window size) instead of sorting again -- several tables indexed by the same scalars, e.g. the A / B1 / B2 / C
+// tables of a Groth16 key (groth16.cpp:88-112 runs four MSMs over one witness).
+//   derive = 0  the lists as they are; the zero-row mask named for this enqueue must be the one that sort was made with
+//   derive = 1  bucket lists of this lane's own, built from that lane's PARTITION without the rows in this enqueue's
+//               zero-row mask (k16_msm_set_zero_row_mask; a superset of the owner's mask): nothing is partitioned again, and
+//               the table's accumulation walks live rows only.  Other lanes may then share THIS lane's lists with derive = 0.
+extern "C" int k16_msm_sort_from_lane(k16_ctx* ctx, int lane, int derive)
+{
+    return k16_guard(ctx, [&]() -> int {
+    if (!ctx || lane < 0 || lane >= k16_ctx::N_LANES) return K16_ERR_ARG;
+    if (derive) {
+        ctx->derive_lane = lane;
+    } else {
+        ctx->reuse_sort      = true;
+        ctx->reuse_sort_lane = lane;
+    }
+    return K16_OK;
+    });
+}
+
 extern "C" int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c)
 {
     return k16_guard(ctx, [&]() -> int {
@@ -547,6 +568,7 @@ extern "C" int k16_msm_abort_all(k16_ctx* ctx)
     ctx->remap_next      = nullptr;
     ctx->skip_next       = nullptr;
     ctx->acc_skip_next   = nullptr;
+    ctx->derive_lane     = -1;
     (void)hipSetDevice(ctx->device);
     for (auto& L : ctx->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);

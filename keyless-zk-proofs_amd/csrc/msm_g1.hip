@@ -23,7 +23,7 @@ int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
         rows = (const k16::G1Aff*)L.ws_conv.p;
         // the conversion rides in the sort's counting pass when there is one (LDS partition sort, no reused sort, no
         // captured graphs -- a graph would pin this call's table pointer); otherwise it is a kernel of its own
-        const bool fuse = n <= (1u << 24) && !ctx->reuse_sort && !ctx->graphs_on && getenv("K16_ATOMIC_SORT") == nullptr &&
+        const bool fuse = n <= (1u << 24) && !ctx->reuse_sort && ctx->derive_lane < 0 && !ctx->graphs_on && getenv("K16_ATOMIC_SORT") == nullptr &&
                           getenv("K16_NO_FUSED_CONVERT") == nullptr;
         if (ctx->lean_sort) {
             // lean sort: the counting pass stays at 25 VGPRs (the fused conversion made it 82), and the conversion is the

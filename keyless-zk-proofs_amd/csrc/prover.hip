@@ -356,6 +356,7 @@ struct k16_prover {
     void* d_skip_ac = nullptr;
     void* d_skip_b  = nullptr;
     bool  b_sort    = false;
+    bool  b_derive  = false; // B1 / B2 accumulate bucket lists of their own, derived from A's partition without their (0,0) rows
 };
 
 // Host side of the compact upload: the context's host threads (k16_ctx_pool) each scan a contiguous range of the witness.
@@ -726,6 +727,14 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         p->b_sort = getenv("K16_B_SORT") && atoi(getenv("K16_B_SORT")) != 0 && p->n_vars >= (1u << 17) && n_b >= p->n_vars / 8;
         if (!p->b_sort)
             for (size_t k = 0; k < mw; k++) ac[k] &= bb[k];
+        // K16_B_DERIVE=1: the one partition (A's) serves every table, and B1 / B2 -- when an eighth or more of the wires are
+        // (0,0) in both -- get bucket lists of their own from it without those rows (k16_msm_sort_from_lane(derive)): pass 3
+        // again (0.2 ms of small kernels on B2's lane), no second partition of the scalars.  Measured against the default
+        // (they read A's lists and step over their (0,0) rows in the accumulation, k_accumulate_skip): B2's accumulation
+        // 1.06 -> 0.65 ms, p50 the same (5.78-5.98 both), four provers 167 against 171-179 proofs/s -- as with K16_B_SORT the
+        // additions saved were not what the proof waits for, and the extra launches cost the other provers; off.
+        p->b_derive = !p->b_sort && getenv("K16_B_DERIVE") && atoi(getenv("K16_B_DERIVE")) != 0 && p->n_vars >= (1u << 17) &&
+                      n_b >= p->n_vars / 8;
         K16_HIP_P(ctx, hipMalloc(&p->d_skip_ac, mb), p);
         K16_HIP_P(ctx, hipMalloc(&p->d_skip_b, mb), p);
         K16_HIP_P(ctx, hipMemcpyAsync(p->d_skip_ac, ac.data(), mb, hipMemcpyHostToDevice, st), p);
@@ -736,6 +745,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
             (void)hipFree(p->d_skip_b);
             p->d_skip_ac = p->d_skip_b = nullptr;
             p->b_sort    = false;
+            p->b_derive  = false;
         }
         // scalar classes (msm_classes.hip): tables with equal masks share a list set
         // (Off by default, K16_CLASSES=1: measured on the synthetic Keyless-shape key the two paths execute the same number of
@@ -1063,14 +1073,22 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, n_wit))) return rc;
         // B1 / B2 on a sort that contains their (0,0) rows: the accumulation steps over them (k_accumulate_skip)
         static const bool acc_skip_on = getenv("K16_NO_ACC_SKIP") == nullptr;
-        const bool        b_skip = acc_skip_on && !p->b_sort && p->d_skip_ac;
+        const bool        b_skip = acc_skip_on && !p->b_sort && !p->b_derive && p->d_skip_ac;
+        if (p->b_derive && !b2_lead) {
+            // B2 first (lane 2): its lists come from lane 0's partition without B's (0,0) rows; B1 (lane 0, after A) reads them
+            ctx->cur_lane = 2;
+            if ((rc = k16_msm_sort_from_lane(ctx, 0, 1))) return rc;
+            ctx->skip_next = (const uint64_t*)p->d_skip_b;
+            if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, n_wit))) return rc;
+        }
+        const bool b_derived = p->b_derive && !b2_lead;
         ctx->cur_lane        = 0;
         ctx->reuse_sort      = true;
-        ctx->reuse_sort_lane = p->b_sort ? 2 : own;
-        ctx->skip_next       = skip_b;
+        ctx->reuse_sort_lane = (p->b_sort || b_derived) ? 2 : own;
+        ctx->skip_next       = b_derived ? (const uint64_t*)p->d_skip_b : skip_b;
         ctx->acc_skip_next   = b_skip ? (const uint64_t*)p->d_zmask[1] : nullptr;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_B1, p->d_wtns, n_wit))) return rc;
-        if (!p->b_sort && !b2_lead) {
+        if (!p->b_sort && !b2_lead && !b_derived) {
             // B2 (G2: long latency-bound fold / reduction chains) gets lane 2 and reads lane 0's sort, so it runs beside B1
             ctx->cur_lane        = 2;
             ctx->reuse_sort      = true;
@@ -1125,7 +1143,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         return K16_OK;
     };
     // results come back in enqueue order: classes A, B2, C, B1, H; bucket path B2, A, C, B1, H with a sort of its own for B,
-    // A, C, B1, B2, H without
+    // A, C, B2, B1, H with derived lists for B (K16_B_DERIVE), A, C, B1, B2, H without
     const bool b2_first = !p->cls && (p->b_sort || getenv("K16_B2_FIRST") != nullptr);
     if (b2_first && (rc = finish_b2())) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_a, nullptr))) return rc;
@@ -1135,11 +1153,13 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     G1Xyzz a_s    = h_mul(pi_a, s_std);
     if (p->cls && (rc = finish_b2())) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_c, nullptr))) return rc;
+    const bool b2_before_b1 = !p->cls && !b2_first && p->b_derive; // enqueued A, C, B2, B1
+    if (b2_before_b1 && (rc = finish_b2())) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pib1, nullptr))) return rc;
     pib1          = h_madd(pib1, p->beta1);
     pib1          = h_add(pib1, d1_s);
     G1Xyzz b1_r   = h_mul(pib1, r_std);
-    if (!p->cls && !b2_first && (rc = finish_b2())) return rc;
+    if (!p->cls && !b2_first && !b2_before_b1 && (rc = finish_b2())) return rc;
     ht("B2 finished");
     // pi_a and pi_b are final: their affine form and decimal strings are made while the GPU still works on the H MSM
     const G1Aff A = to_affine(pi_a);

@@ -35,7 +35,7 @@ SYMBOLS = [
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
-    "k16_msm_zero_row_mask", "k16_msm_set_zero_row_mask", "k16_scalar_classes_create", "k16_scalar_classes_destroy", "k16_scalar_classes_build", "k16_scalar_classes_counts", "k16_msm_enqueue_classified",
+    "k16_msm_zero_row_mask", "k16_msm_set_zero_row_mask", "k16_msm_sort_from_lane", "k16_scalar_classes_create", "k16_scalar_classes_destroy", "k16_scalar_classes_build", "k16_scalar_classes_counts", "k16_msm_enqueue_classified",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_fullprover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
@@ -95,6 +95,7 @@ def load():
     L.k16_points_sum.argtypes = [i32, vp, u64, vp, vp]
     L.k16_msm_zero_row_mask.argtypes = [vp, i32, vp, u64, vp]
     L.k16_msm_set_zero_row_mask.argtypes = [vp, vp]
+    L.k16_msm_sort_from_lane.argtypes = [vp, i32, i32]
     L.k16_scalar_classes_create.argtypes = [vp, u64, i32, C.POINTER(vp)]
     L.k16_scalar_classes_destroy.argtypes = [vp]
     L.k16_scalar_classes_destroy.restype = None
@@ -261,6 +262,9 @@ class Context:
 
     def msm_set_zero_row_mask(self, d_mask):
         self._chk(self.L.k16_msm_set_zero_row_mask(self.h, d_mask.ptr if d_mask is not None else None))
+
+    def msm_sort_from_lane(self, lane, derive=False):
+        self._chk(self.L.k16_msm_sort_from_lane(self.h, lane, 1 if derive else 0))
 
     def classes_create(self, max_n, max_sets=1):
         h = C.c_void_p()

@@ -253,15 +253,92 @@ def test_bucket_sort_leaves_out_zero_rows_through_the_mask(ctx, group):
         d.free()
 
 
-@pytest.mark.parametrize("mode", ["classes", "b_sort"])
+@pytest.mark.parametrize("group", [0, 1])
+@pytest.mark.parametrize("window_bits", [13, 0])
+def test_tables_that_share_their_scalars_share_or_derive_the_bucket_sort(ctx, group, window_bits):
+    """k16_msm_sort_from_lane: three tables indexed by ONE scalar array (groth16.cpp:88-112: A, B1, B2, C over the witness).
+    Lane 0 sorts for table 0; lane 2 DERIVES lists of its own from lane 0's partition without the (0,0) rows of tables 1 and
+    2 (half of them); lane 1 reads lane 2's lists as they are.  Every sum equals the oracle's multiexp of that table.
+    window_bits 0 = automatic (c = 16 at these sizes: lane 0's sort is the staged five-byte one, whose partition cannot be
+    read again -- the derived request then reads lane 0's lists and steps over the rows in the accumulation)."""
+    import k16
+    n = 1 << 17 if group == 0 else 1 << 16
+    s = np_scalars(23 + group, n, "witness")
+    s[n // 2: n // 2 + 4000] = np_scalars(5, 4000, "uniform")
+    aff = k16.AFF_BYTES[group]
+    rs = np.random.RandomState(8 + group)
+    dead = rs.rand(n) < 0.5
+    dead[:70] = True
+    tabs = []
+    for t in range(3):
+        d = ctx.synth_points(group, 31 + t, n)
+        b = d.download(np.uint8, (n, aff)).copy()
+        d.free()
+        if t:
+            b[dead] = 0
+        else:
+            b[rs.rand(n) < 0.01] = 0
+        tabs.append(b)
+    d_s = ctx.to_device(s)
+    d_tabs, masks = [], []
+    for b in tabs:
+        d_b = ctx.to_device(b)
+        d_tabs.append(ctx.bases_prepare(group, d_b, n))
+        d_b.free()
+        masks.append(ctx.zero_row_mask(group, d_tabs[-1], n))
+    want = [ol.msm(group, b, s, nthreads=8)[1] for b in tabs]
+    ctx.set_window_bits(window_bits)
+    try:
+        for rep in range(2):                       # the second round replays captured graphs where they are on
+            ctx.set_lane(0)
+            ctx.msm_enqueue_prepared(group, d_tabs[0], d_s, n)
+            ctx.set_lane(2)
+            ctx.msm_sort_from_lane(0, derive=True)
+            ctx.msm_set_zero_row_mask(masks[1])
+            ctx.msm_enqueue_prepared(group, d_tabs[1], d_s, n)
+            ctx.set_lane(1)
+            ctx.msm_sort_from_lane(2 if window_bits else 0)
+            ctx.msm_set_zero_row_mask(masks[1] if window_bits else None)
+            ctx.msm_enqueue_prepared(group, d_tabs[2], d_s, n)
+            ctx.set_lane(0)
+            for t in range(3):
+                _, got = ctx.msm_finish(group)
+                assert got == want[t], (rep, t)
+        # no matching sort on the named lane, the lane itself, a derived sort without a mask: refused, nothing left pending
+        ctx.set_lane(2)
+        ctx.msm_sort_from_lane(3, derive=True)
+        ctx.msm_set_zero_row_mask(masks[1])
+        with pytest.raises(k16.K16Error):
+            ctx.msm_enqueue_prepared(group, d_tabs[1], d_s, n)
+        ctx.msm_sort_from_lane(2, derive=True)
+        ctx.msm_set_zero_row_mask(masks[1])
+        with pytest.raises(k16.K16Error):
+            ctx.msm_enqueue_prepared(group, d_tabs[1], d_s, n)
+        ctx.msm_sort_from_lane(0, derive=True)
+        with pytest.raises(k16.K16Error):
+            ctx.msm_enqueue_prepared(group, d_tabs[1], d_s, n)
+        assert ctx.msm_pending() == 0
+        ctx.set_lane(0)
+        ctx.msm_enqueue_prepared(group, d_tabs[1], d_s, n)     # and the context is as usable as before
+        _, got = ctx.msm_finish(group)
+        assert got == want[1]
+    finally:
+        ctx.set_lane(0)
+        ctx.set_window_bits(0)
+        ctx.sync()
+    for d in d_tabs + masks + [d_s]:
+        d.free()
+
+
+@pytest.mark.parametrize("mode", ["classes", "b_sort", "b_derive"])
 def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, monkeypatch, mode):
     """BASELINE config 3 at its stated size (nVars 1,343,588, N = 2^21, B1 / B2 half (0,0)) with the witness MSMs taking
-    the two paths that are off by default -- scalar classes (K16_CLASSES=1) and a bucket sort of B's own without its (0,0)
-    rows (K16_B_SORT=1): proof JSON byte-equal to the CPU oracle's (RS/groth16.cpp:41-360), for two witnesses on one
+    the paths that are off by default -- scalar classes (K16_CLASSES=1), a bucket sort of B's own without its (0,0)
+    rows (K16_B_SORT=1), bucket lists for B1 / B2 derived from A's partition without them (K16_B_DERIVE=1): proof JSON byte-equal to the CPU oracle's (RS/groth16.cpp:41-360), for two witnesses on one
     prover."""
     import bench
     import k16
-    monkeypatch.setenv("K16_CLASSES" if mode == "classes" else "K16_B_SORT", "1")
+    monkeypatch.setenv({"classes": "K16_CLASSES", "b_sort": "K16_B_SORT", "b_derive": "K16_B_DERIVE"}[mode], "1")
     n_vars, N, n_coefs = bench.KEYLESS["n_vars"], bench.KEYLESS["domain"], bench.KEYLESS["n_coefs"]
     zk = str(tmp_path / "keyless_shape.zkey")
     wt = str(tmp_path / "keyless_shape.wtns")
