@@ -342,12 +342,14 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         allv = [None] * world
         dist.all_gather_object(allv, lat)
         lat = [x for l in allv for x in l]
-    # throughput mode (rank 0 reports, every rank runs it so that the GPUs stay symmetric): four provers -- own context,
-    # streams and resident key each -- share this GPU and prove concurrently from four threads, the deployment of
-    # INTEGRATION.md section 4 (K16_DEVICES=0,0,0,0 behind one FullProver).  One proof's upload / chain / H MSM then runs
+    # throughput mode (rank 0 reports, every rank runs it so that the GPUs stay symmetric): two provers -- own context,
+    # streams and resident key each -- share this GPU and prove concurrently from two threads, the deployment of
+    # INTEGRATION.md section 4 (K16_DEVICES=0,0 behind one FullProver).  One proof's upload / chain / H MSM then runs
     # under another's; latency per proof rises, proofs per second too.
     thr = None
-    n_conc = int(os.environ.get("K16_BENCH_PROVERS", "4"))   # measured: 3 -> 158-161, 4 -> 172-177, 5 / 6 -> 172-175 proofs/s
+    # measured, round 4 (profiles/r04/throughput_provers_sweep.log): 2 -> 180-184, 3 -> 175-178, 4 -> 170-172, 6 / 8 -> 170 proofs/s,
+    # with p50 10.5 / 17 / 23.5 ms: two provers fill the chip (2.16-2.18 GHz at 1140 W, profiles/r04/clocks_under_proof_load.log)
+    n_conc = int(os.environ.get("K16_BENCH_PROVERS", "2"))
     if n_conc > 1:
         import threading
         others = [k16.Context(ctx_device(ctx)) for _ in range(n_conc - 1)]

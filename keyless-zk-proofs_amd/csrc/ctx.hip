@@ -617,7 +617,7 @@ extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, 
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
     const bool lazy = op == K16_OP_LAZY_ADDMUL || op == K16_OP_LAZY_SUBMUL;
-    if (lazy && (field != K16_FQ9 && field != K16_FR9 || kb || ka > 14 || !h_b)) return K16_ERR_ARG;
+    if (lazy && ((field != K16_FQ9 && field != K16_FR9) || kb || ka > 14 || !h_b)) return K16_ERR_ARG;
     if (!lazy && (ka || kb) && (field < K16_FQ9 || field == K16_FQ2N || ka > 6 || kb > 6)) return K16_ERR_ARG;
     if (!lazy && op > K16_OP_FROMMONT) return K16_ERR_ARG;
     if (field == K16_FQ2N && op > K16_OP_SQR) return K16_ERR_ARG;

@@ -1,7 +1,8 @@
 """Differential fuzz of the round-4 MSM paths against the CPU oracle: the scalar-class MSM (k16_scalar_classes_* /
 k16_msm_enqueue_classified: 1-4 tables with their own (0,0) rows sharing one classification, exact / generous / read-back
 wide bounds), the bucket sort with a zero-row mask (k16_msm_set_zero_row_mask), and -- at sizes of 2^16 and above with the
-automatic window size (c = 16) -- the five-byte staged sort.  Random sizes, both groups, scalar kinds mixed in stretches,
+automatic window size (c = 16) -- the five-byte staged sort, and bucket lists shared between lanes or derived from another
+lane's partition (k16_msm_sort_from_lane).  Random sizes, both groups, scalar kinds mixed in stretches,
 random (0,0) rows, duplicates.      python tools/classes_fuzz.py [cases] [seed]"""
 import json
 import os
@@ -28,7 +29,7 @@ for g in (0, 1):
     d = ctx.synth_points(g, 11, NMAX[g])
     pool[g] = d.download(np.uint8, (NMAX[g], k16.AFF_BYTES[g])).copy()
     d.free()
-bad, t0, counts = [], time.time(), {"classified": 0, "masked_bucket": 0, "plain": 0}
+bad, t0, counts = [], time.time(), {"classified": 0, "masked_bucket": 0, "plain": 0, "shared_or_derived": 0}
 for c in range(cases):
     g = int(rs.rand() < 0.3)
     n = int(rs.choice([0, 1, 63, 64, 65, 2047, 2048, 2049, 65535, 65536, 65537, 131072])) if rs.rand() < 0.4 else int(rs.randint(0, NMAX[g] + 1))
@@ -87,12 +88,34 @@ for c in range(cases):
             counts["masked_bucket"] += 1
             if got != want[0]:
                 bad.append((c, "masked_bucket", g, n, 0))
+            if n_tabs >= 2:
+                # k16_msm_sort_from_lane: lane 0 sorts for table 0 (forced window size on every other case: the plain
+                # partition, else the staged one at n >= 2^16), lane 2 derives lists without table 1's (0,0) rows from lane 0's
+                # partition (or falls back to stepping over them), lane 1 reads lane 2's lists for table 1 again
+                wb = int(rs.choice([0, 0, 9, 13]))
+                ctx.set_window_bits(wb)
+                ctx.set_lane(0)
+                ctx.msm_enqueue_prepared(g, d_tabs[0], d_s, n)
+                ctx.set_lane(2)
+                ctx.msm_sort_from_lane(0, derive=True)
+                ctx.msm_set_zero_row_mask(masks[1])
+                ctx.msm_enqueue_prepared(g, d_tabs[1], d_s, n)
+                ctx.set_lane(1)
+                ctx.msm_sort_from_lane(0)
+                ctx.msm_enqueue_prepared(g, d_tabs[0], d_s, n)
+                ctx.set_lane(0)
+                ctx.set_window_bits(0)
+                for t in (0, 1, 0):
+                    _, got = ctx.msm_finish(g)
+                    counts["shared_or_derived"] += 1
+                    if got != want[t]:
+                        bad.append((c, "shared_or_derived", g, n, t, wb))
     finally:
         ctx.sync()
         ctx.classes_destroy(cls)
         for d in d_tabs + masks + [d_s]:
             if d is not None:
                 d.free()
-print(json.dumps({"fuzz": "scalar-class MSM, masked bucket sort, staged sort vs oracle", "cases": cases, "seed": seed, "checks": counts,
+print(json.dumps({"fuzz": "scalar-class MSM, masked bucket sort, staged sort, shared / derived bucket lists vs oracle", "cases": cases, "seed": seed, "checks": counts,
                   "mismatches": bad, "seconds": round(time.time() - t0, 1)}))
 sys.exit(1 if bad else 0)
