@@ -140,6 +140,9 @@ struct k16_ctx {
     // zero-row mask of the NEXT MSM's own table, applied in its accumulation (for a table that reuses another table's sort)
     const uint64_t* acc_skip_next = nullptr;
     int             derive_lane   = -1; // next enqueue: bucket lists of its own from that lane's partition, minus skip_next's rows
+    // next enqueue: its scalars do not exist yet -- scalar i = fromMontgomery(hs_next[0][i] * hs_next[1][i] - hs_next[2][i]) over Fr
+    // (packed R' values), formed by the sort's counting pass and written to d_scalars (the prover's H MSM, groth16.cpp:266-283)
+    const void*     hs_next[3]    = {nullptr, nullptr, nullptr};
     // K16_SERIALIZE_ACC=1 (bench.py sets it): a lane's bucket accumulation waits for the previous lane's.  Two of these
     // chip-filling kernels never overlap anyway (kernel traces: the second starts when the first ends), so nothing is
     // lost, but the HIP events that time the kernel on its own stream then bracket its execution only -- without the fence

@@ -569,6 +569,7 @@ extern "C" int k16_msm_abort_all(k16_ctx* ctx)
     ctx->skip_next       = nullptr;
     ctx->acc_skip_next   = nullptr;
     ctx->derive_lane     = -1;
+    ctx->hs_next[0] = ctx->hs_next[1] = ctx->hs_next[2] = nullptr;
     (void)hipSetDevice(ctx->device);
     for (auto& L : ctx->lanes)
         if (L.stream) (void)hipStreamSynchronize(L.stream);

@@ -981,8 +981,14 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     // reversal] into d_t[k]), then the forward passes in place on d_t[k] -- six launches for the six transforms
     Fr* src[3] = {p->d_a, p->d_b, p->d_c};
     if ((rc = k16_ntt_coset_chain(ctx, src, p->d_t, 3, N, p->ntt, p->d_shift9, s2))) return rc;
-    // the H scalars go to d_a (free since the inverse transform's last pass)
-    hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_t[0], p->d_t[1], p->d_t[2], N);
+    // the H scalars go to d_a (free since the inverse transform's last pass): written by the H MSM's own counting pass when it
+    // is the fixed-base one (ctx->hs_next below), by k_hscalars otherwise
+    // (K16_FUSED_HSCALARS=1; measured: the counting pass grows from 40 to 97 us, the 53 us kernel and its gap disappear -- 4 us
+    // less between the chain's end and the end of the counting pass, profiles/r04/proof_timeline_fused_h_scalars.txt: the
+    // scalars' arithmetic, 46 us of multiply issue, moves with them; off)
+    static const bool hs_fuse = getenv("K16_FUSED_HSCALARS") != nullptr;
+    const bool        hs_in_sort = hs_fuse && p->d_Htab != nullptr;
+    if (!hs_in_sort) hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_t[0], p->d_t[1], p->d_t[2], N);
     K16_HIP(ctx, hipGetLastError());
     K16_HIP(ctx, hipEventRecord(p->ev_h, s2));
     ht("chain enqueued");
@@ -1108,6 +1114,11 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     ctx->cur_lane = 1;
     K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_h, 0));
     if (p->d_Htab) {
+        if (hs_in_sort) {
+            ctx->hs_next[0] = p->d_t[0];
+            ctx->hs_next[1] = p->d_t[1];
+            ctx->hs_next[2] = p->d_t[2];
+        }
         if ((rc = k16_msm_enqueue_fixed_base(ctx, K16_G1, p->d_Htab, p->d_a, N))) return rc;
     } else if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_H, p->d_a, N))) {
         return rc;

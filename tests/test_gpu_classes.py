@@ -330,15 +330,16 @@ def test_tables_that_share_their_scalars_share_or_derive_the_bucket_sort(ctx, gr
         d.free()
 
 
-@pytest.mark.parametrize("mode", ["classes", "b_sort", "b_derive"])
+@pytest.mark.parametrize("mode", ["classes", "b_sort", "b_derive", "fused_h_scalars"])
 def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, monkeypatch, mode):
     """BASELINE config 3 at its stated size (nVars 1,343,588, N = 2^21, B1 / B2 half (0,0)) with the witness MSMs taking
     the paths that are off by default -- scalar classes (K16_CLASSES=1), a bucket sort of B's own without its (0,0)
-    rows (K16_B_SORT=1), bucket lists for B1 / B2 derived from A's partition without them (K16_B_DERIVE=1): proof JSON byte-equal to the CPU oracle's (RS/groth16.cpp:41-360), for two witnesses on one
+    rows (K16_B_SORT=1), bucket lists for B1 / B2 derived from A's partition without them (K16_B_DERIVE=1), the H scalars formed by the H MSM's
+    counting pass (K16_FUSED_HSCALARS=1): proof JSON byte-equal to the CPU oracle's (RS/groth16.cpp:41-360), for two witnesses on one
     prover."""
     import bench
     import k16
-    monkeypatch.setenv({"classes": "K16_CLASSES", "b_sort": "K16_B_SORT", "b_derive": "K16_B_DERIVE"}[mode], "1")
+    monkeypatch.setenv({"classes": "K16_CLASSES", "b_sort": "K16_B_SORT", "b_derive": "K16_B_DERIVE", "fused_h_scalars": "K16_FUSED_HSCALARS"}[mode], "1")
     n_vars, N, n_coefs = bench.KEYLESS["n_vars"], bench.KEYLESS["domain"], bench.KEYLESS["n_coefs"]
     zk = str(tmp_path / "keyless_shape.zkey")
     wt = str(tmp_path / "keyless_shape.wtns")
