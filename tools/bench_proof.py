@@ -42,6 +42,7 @@ def main():
                     help="also drive the C++ FullProver facade (tests/cpp/fullprover_harness.cpp) with this many threads over "
                          "a pool of as many provers on GPU 0 (K16_DEVICES=0,0,..)")
     ap.add_argument("--no-stats", action="store_true", help="no per-stage HIP events inside the timed proofs")
+    ap.add_argument("--random-rs", action="store_true", help="blinding scalars from the OS CSPRNG (the production path) instead of two fixed 64-bit values")
     ap.add_argument("--concurrent", type=int, default=1, help="throughput mode: this many provers (own context, streams) share the GPU")
     args = ap.parse_args()
     n_vars = max(int(1343588 * args.scale), 8)
@@ -67,7 +68,7 @@ def main():
     t_all = time.perf_counter()
     for i in range(args.proofs):
         t1 = time.perf_counter()
-        js = prover.prove_mem(wits[i % len(wits)], r, s)
+        js = prover.prove_mem(wits[i % len(wits)]) if args.random_rs else prover.prove_mem(wits[i % len(wits)], r, s)
         lat.append((time.perf_counter() - t1) * 1e3)
         dev.append(prover.last_device_ms)
     total = time.perf_counter() - t_all
