@@ -353,6 +353,8 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
     if n_conc > 1:
         import threading
         others = [k16.Context(ctx_device(ctx)) for _ in range(n_conc - 1)]
+        for c in [ctx] + others:
+            c.set_option(k16.OPT_SHARED_GPU, 1)      # what FullProver does for K16_DEVICES=0,0 (include/k16.h)
         provers = [prover] + [k16.Prover(c, zpath) for c in others]
         for pv in provers[1:]:
             pv.prove_mem(wits[0], r, s)
@@ -384,6 +386,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             pv.close()
         for c in others:
             c.close()
+        ctx.set_option(k16.OPT_SHARED_GPU, 0)
     out = None
     if rank == 0:
         p50 = float(np.median(lat))

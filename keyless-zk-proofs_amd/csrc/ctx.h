@@ -140,6 +140,9 @@ struct k16_ctx {
     // zero-row mask of the NEXT MSM's own table, applied in its accumulation (for a table that reuses another table's sort)
     const uint64_t* acc_skip_next = nullptr;
     int             derive_lane   = -1; // next enqueue: bucket lists of its own from that lane's partition, minus skip_next's rows
+    // workgroups of a 1024-element NTT pass per CU (ntt.hip): 4 is what fits; 3 (K16_OPT_SHARED_GPU) leaves registers for a wave of
+    // another prover's bucket accumulation beside them
+    unsigned        ntt_wg_per_cu = 4, ntt_wg_per_cu_default = 4;
     // next enqueue: its scalars do not exist yet -- scalar i = fromMontgomery(hs_next[0][i] * hs_next[1][i] - hs_next[2][i]) over Fr
     // (packed R' values), formed by the sort's counting pass and written to d_scalars (the prover's H MSM, groth16.cpp:266-283)
     const void*     hs_next[3]    = {nullptr, nullptr, nullptr};

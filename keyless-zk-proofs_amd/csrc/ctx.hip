@@ -69,6 +69,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
                    hipEventCreateWithFlags(&c->lanes[i].lvl1_done, hipEventDisableTiming) == hipSuccess &&
                    hipEventCreateWithFlags(&c->lanes[i].tail_done, hipEventDisableTiming) == hipSuccess;
     if (const char* e = getenv("K16_SERIALIZE_ACC")) c->serialize_acc = atoi(e) != 0;
+    if (const char* e = getenv("K16_NTT_WG_PER_CU")) c->ntt_wg_per_cu = c->ntt_wg_per_cu_default = (unsigned)std::max(1, std::min(4, atoi(e)));
     if (const char* e = getenv("K16_WSUM_MLOG_CAP")) c->wsum_mlog_cap = (unsigned)atoi(e);
     if (const char* e = getenv("K16_GRAPHS")) c->graphs_on = atoi(e) != 0;
     if (const char* e = getenv("K16_ACC_FENCE")) c->acc_fence_mode = atoi(e);
@@ -213,6 +214,13 @@ extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
         // (the lean sort -- every sort kernel in <= 32 VGPRs, resident beside another lane's accumulation -- is NOT switched
         // on here: measured, it moves the sort under the accumulation but the step does not get shorter, the chip being
         // power-limited during a pipelined run (profiles/r03/lean_sort_and_power.md); K16_LEAN_SORT=1 selects it)
+        return K16_OK;
+    case K16_OPT_SHARED_GPU:
+        // several provers (contexts) prove on this GPU at once: proofs per second over the latency of one.  The NTT passes
+        // then keep three workgroups per CU instead of four, which leaves a SIMD the registers for a wave of another
+        // prover's bucket accumulation: +2.5-3 % proofs/s with two provers, +0-0.3 ms on a proof alone
+        // (profiles/r04/ab_ntt_wg_per_cu.log)
+        c->ntt_wg_per_cu = value ? std::min(3u, c->ntt_wg_per_cu_default) : c->ntt_wg_per_cu_default;
         return K16_OK;
     default: return K16_ERR_ARG;
     }

@@ -112,6 +112,11 @@ public:
             s->prover = nullptr;
             s->ctx    = nullptr;
             ok = k16_ctx_create(s->device, &s->ctx) == K16_OK && k16_prover_create(s->ctx, zkey_path.c_str(), &s->prover) == K16_OK;
+            if (ok) {
+                int sharing = 0;
+                for (auto& o : slots) sharing += o.device == s->device;
+                if (sharing > 1) (void)k16_ctx_set_option(s->ctx, K16_OPT_SHARED_GPU, 1);
+            }
         } catch (...) {
             ok = false;
         }
@@ -204,6 +209,12 @@ FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullPro
                 return;
             }
             p->slots.push_back(s);
+        }
+        // entries that share a GPU prove there at the same time: throughput tuning (include/k16.h, K16_OPT_SHARED_GPU)
+        for (auto& s : p->slots) {
+            int sharing = 0;
+            for (auto& o : p->slots) sharing += o.device == s.device;
+            if (sharing > 1) (void)k16_ctx_set_option(s.ctx, K16_OPT_SHARED_GPU, 1);
         }
     } catch (...) {
         delete p;

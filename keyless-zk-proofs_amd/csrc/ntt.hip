@@ -382,9 +382,23 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
         const size_t   telem = (size_t)1 << (TL + K);
         const size_t   lds   = telem * sizeof(Fr9) + (tail ? (telem >> 6) * 4 + 16 : 0);
         const bool     big = lds > 48 * 1024; // 512 threads per workgroup, dynamic LDS above the default limit
+        // K16_OPT_SHARED_GPU / K16_NTT_WG_PER_CU=3: the 1024-element passes ask for a third of the CU's LDS instead of the 36 KB
+        // they use, so that three workgroups are resident per CU instead of four -- 312 of a SIMD's 512 registers, which leaves
+        // room for a wave of a bucket accumulation (159) beside them
+        const unsigned wg_per_cu = ctx->ntt_wg_per_cu;
+        const size_t lds_launch = (!big && wg_per_cu < 4) ? std::max<size_t>(lds, (size_t)(160 * 1024 / wg_per_cu) - 1024) : lds;
 #define K16_NTT_LAUNCH(CI, CO, TA)                                                                                              \
     do {                                                                                                                        \
-        if (big) {                                                                                                              \
+        if (!big && lds_launch > lds) {                                                                                         \
+            static bool attr2 = false;                                                                                          \
+            if (!attr2) {                                                                                                       \
+                (void)hipFuncSetAttribute((const void*)k_ntt_pass9<CI, CO, TA, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          160 * 1024);                                                                          \
+                attr2 = true;                                                                                                   \
+            }                                                                                                                   \
+            hipLaunchKernelGGL((k_ntt_pass9<CI, CO, TA, 256>), grid, dim3(256), lds_launch, st, pp, tab->roots9, s0, K, TL,     \
+                               tab->s, logn, shift9);                                                                           \
+        } else if (big) {                                                                                                              \
             static bool attr = false;                                                                                           \
             if (!attr) {                                                                                                        \
                 (void)hipFuncSetAttribute((const void*)k_ntt_pass9<CI, CO, TA, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("K16_LIB_PATH") or os.path.join(HERE, "libk16.so")  # 
 G1, G2 = 0, 1
 OPT_PIPELINED_MSM = 1
 OPT_GRAPHS = 2
+OPT_SHARED_GPU = 3
 FQ, FR = 0, 1
 FQ9, FR9, FQ2N = 2, 3, 4          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
 G1_ENG9, G2_ENG2N = 2, 3

@@ -43,6 +43,8 @@ def test_eight_provers_share_one_host_pool_and_keep_the_throughput():
     os_threads_after_one = _threads_of_process()
     ref = provers[0].prove_mem(wit, r, s)
     provers += [k16.Prover(k16.Context(0), zpath) for _ in range(7)]
+    for pv in provers:                      # what FullProver does for K16_DEVICES=0,0,...: same proofs, throughput tuning
+        pv.ctx.set_option(k16.OPT_SHARED_GPU, 1)
     assert L.k16_host_threads() == workers_after_one            # one pool, created once
     assert 0 < workers_after_one + 1 <= max(usable, 2)
     # (HIP itself starts a few threads per context; the library's own contribution must not grow with the provers)

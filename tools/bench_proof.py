@@ -81,7 +81,11 @@ def main():
     if args.concurrent > 1:
         # throughput mode: several provers on one GPU (e.g. one per service worker); the GPU interleaves their kernels
         import threading
-        provers = [prover] + [k16.Prover(k16.Context(0), zpath) for _ in range(args.concurrent - 1)]
+        octx = [k16.Context(0) for _ in range(args.concurrent - 1)]
+        if not os.environ.get("K16_BENCH_NO_SHARED_OPT"):
+            for c in [ctx] + octx:
+                c.set_option(k16.OPT_SHARED_GPU, 1)      # what FullProver does for K16_DEVICES=0,0
+        provers = [prover] + [k16.Prover(c, zpath) for c in octx]
         for pv in provers:
             pv.prove_mem(wits[0], r, s)
         lats = [[] for _ in provers]
