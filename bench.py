@@ -109,6 +109,19 @@ def scalar_times_g(ctx, k16, k):
 
 
 # ---------------------------------------------------------------------------------------------------- CPU baseline
+KERNEL_SOURCES = ("csrc/msm_kernels.inc", "csrc/bn254_fq9.h", "csrc/bn254_field.h", "csrc/bn254_curve.h", "csrc/msm_g1.hip")
+
+
+def kernel_sources_sha16():
+    """Digest of the files that make up k_accumulate<Eng9> (what profiles/pmc_traffic.json's counters belong to)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "keyless-zk-proofs_amd", rel), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask, cut by a cgroup CPU quota if there is one (os.cpu_count() reports
     the machine's cores even inside a container that is allowed a few of them -- 64 OpenMP threads on 16 allowed cores is
@@ -530,9 +543,50 @@ def cold_probe_child(args):
     return 0
 
 
-def cold_probe(args):
+def warm_only_child(args):
+    """A FRESH process doing exactly what the driver's flags say and nothing more: W warm-up steps, then K timed steps --
+    no prewarm.  Reported beside the headline as `value_driver_warmup_only`: the headline's timed region
+    starts after `prewarm_steps` more MSMs, when workspaces exist and the clocks have ramped up."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import k16
+    ctx = k16.Context(0)
+    ctx.set_option(k16.OPT_PIPELINED_MSM, 1)
+    n = 1 << args.log2n
+    d_bases = ctx.synth_points(k16.G1, 0, n)
+    d_scalars = ctx.to_device(uniform_scalars(n, seed=0xD1B5))
+    ctx.sync()
+    depth = 4
+    lane = [0]
+
+    def run(steps):
+        def enq():
+            ctx.set_lane(lane[0])
+            lane[0] = (lane[0] + 1) % depth
+            ctx.msm_enqueue(k16.G1, d_bases, d_scalars, n)
+        for k in range(min(depth - 1, steps)):
+            enq()
+        for k in range(steps):
+            if k + depth - 1 < steps:
+                enq()
+            ctx.msm_finish(k16.G1)
+
+    run(args.warmup)
+    ctx.sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    ctx.sync()
+    el = time.perf_counter() - t0
+    print(json.dumps({"value": n * args.steps / el, "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup,
+                      "note": "fresh process, the driver's W warm-up steps and K timed steps only (no prewarm), one host thread"}),
+          flush=True)
+    ctx.close()
+    return 0
+
+
+def cold_probe(args, flag="--cold-probe"):
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-probe", "--log2n", str(args.log2n)],
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), flag, "--log2n", str(args.log2n),
+                              "--steps", str(args.steps), "--warmup", str(args.warmup)],
                              capture_output=True, text=True, timeout=300)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         return json.loads(line[-1]) if line else {"error": (out.stderr or out.stdout)[-300:]}
@@ -552,9 +606,12 @@ def main():
     ap.add_argument("--proof-scale", type=float, default=1.0, help="shrink the synthetic circuit (1.0 = Keyless shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cold-probe", action="store_true", help=argparse.SUPPRESS)   # child of the main run, see cold_probe()
+    ap.add_argument("--warm-only-probe", action="store_true", help=argparse.SUPPRESS)   # child: W warm-up + K steps, no prewarm
     args = ap.parse_args()
     if args.cold_probe:
         return cold_probe_child(args)
+    if args.warm_only_probe:
+        return warm_only_child(args)
 
     n_gpus = max(args.gpus, 1)
     if "WORLD_SIZE" not in os.environ and n_gpus > 1:
@@ -567,6 +624,7 @@ def main():
 
     # the cold figures come from a child process that runs (and ends) before this one touches the GPU
     cold = cold_probe(args) if (world == 1 and args.mode == "weak" and not os.environ.get("K16_BENCH_NO_COLD")) else None
+    warm_only = cold_probe(args, "--warm-only-probe") if cold is not None else None
 
     # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Four MSM lanes fill
     # them; with torch.distributed the RCCL stream would have to share one with a lane (measured at world size 1:
@@ -617,6 +675,12 @@ def main():
 
     import sharding
 
+    # K16_BENCH_SHARDS=k (strong mode, one process): the MSM through k16_msm_sharded_* -- k shards over the visible devices
+    # (round-robin; on a one-GPU box k contexts on device 0), scalars handed over in HOST memory every step
+    shards_obj, shard_devices = None, []
+    if strong and world == 1 and int(os.environ.get("K16_BENCH_SHARDS", "0")) > 0:
+        ndev = max(1, k16.load().k16_device_count())
+        shard_devices = [r % ndev for r in range(int(os.environ["K16_BENCH_SHARDS"]))]
     if strong:
         total = 1 << args.total_log2n
         lo, hi = sharding.shard_range(total, world, rank)
@@ -626,8 +690,18 @@ def main():
         n, start = 1 << args.log2n, rank * (1 << args.log2n)
         scalars = uniform_scalars(n, seed=0xD1B5 + rank)
     # this rank's shard: bases (start + i + 1) * G, own scalars
-    d_bases = ctx.synth_points(k16.G1, start, n)
-    d_scalars = ctx.to_device(scalars)
+    if shard_devices:
+        shards_obj = k16.ShardedMsm(shard_devices, k16.G1, n)
+        for r in range(shards_obj.count()):
+            slo, shi = shards_obj.shard_range(r)
+            sc = shards_obj.shard_ctx(r)
+            d = sc.synth_points(k16.G1, slo, shi - slo)
+            shards_obj.set_bases_device(r, d)
+            d.free()
+        d_bases, d_scalars = ctx.alloc(16), ctx.alloc(16)
+    else:
+        d_bases = ctx.synth_points(k16.G1, start, n)
+        d_scalars = ctx.to_device(scalars)
 
     if os.environ.get("K16_BENCH_C"):           # experiments only: override the automatic window size
         ctx.set_window_bits(int(os.environ["K16_BENCH_C"]))
@@ -652,7 +726,26 @@ def main():
 
     pending_x = []   # the previous step's exchange, still in flight
 
+    # strong mode (BASELINE config 5: ONE MSM sharded over the ranks) exchanges through the library's own C entry points
+    # (k16_rank_comm_*: ncclAllGather issued by libk16.so, sharding.RankExchange) -- the path a C++ service has; the weak
+    # mode's per-step exchange stays on torch.distributed's asynchronous all_gather, which it overlaps with the next step.
+    # K16_BENCH_EXCHANGE=c|torch overrides; a C leg that cannot start (no RCCL library) falls back and says so.
+    c_exchange, c_exchange_note = None, None
+    want_c = os.environ.get("K16_BENCH_EXCHANGE", "c" if strong else "torch") == "c"
+    if dist is not None and want_c and not SHARE_GPU:
+        try:
+            c_exchange = sharding.RankExchange(dist, ctx)
+        except Exception as e:
+            c_exchange_note = "C exchange unavailable (%r): torch.distributed all_gather instead" % (e,)
+        ok = torch.tensor([1 if c_exchange is not None else 0], device=XDEV)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
+        if int(ok.item()) == 0 and c_exchange is not None:
+            c_exchange.close()
+            c_exchange = None
+
     def exchange(xyzz):
+        if c_exchange is not None:
+            return c_exchange.exchange_and_fold(k16.G1, xyzz)[0]
         if dist is not None:
             # the path's one exchange: start this step's all_gather, complete the previous step's (it ran under the
             # GPU work enqueued in between); run() drains the last one inside the timed region
@@ -679,7 +772,10 @@ def main():
         waits.  K16_BENCH_THREADED=0: everything from this thread."""
         depth = depth_cell[0]
         res = None
-        if chunked:
+        if shards_obj is not None:
+            for k in range(steps):
+                res = shards_obj.run(scalars)[0]
+        elif chunked:
             for k in range(steps):
                 res = exchange(ctx.msm_device(k16.G1, d_bases, d_scalars, n)[0])
         # One host path for N = 1 and N > 1 (a 1 -> 8 scaling curve must not mix a host-side change into "scaling"): the
@@ -795,7 +891,38 @@ def main():
         if not result_checked and not os.environ.get("K16_BENCH_NOCHECK"):   # (probe runs produce wrong results on purpose)
             raise SystemExit("bench.py: MSM result differs from the closed form sum s_i (i+1) * G")
 
+    # ---- secondary figure: the shape of Curve::multiMulByScalar's contract (curve.hpp:209-215) -- scalars arrive in HOST memory
+    # (page-locked) every call, the result goes back to the host; bases stay resident (a prover's tables are static).  One MSM
+    # at a time: upload, sort, accumulate, reduce, combine, no overlap between calls.  PCIe-inclusive, never `value`.
+    host_leg = None
+    if rank == 0 and not strong and not chunked and not os.environ.get("K16_BENCH_NO_HOST_LEG"):
+        try:
+            pinned = torch.from_numpy(scalars).pin_memory()
+            hp = pinned.numpy()
+            d_s2 = ctx.alloc(hp.nbytes)
+            ctx.set_lane(0)
+            reps = 10
+            for k in range(2 + reps):
+                if k == 2:
+                    ctx.sync()
+                    th0 = time.perf_counter()
+                d_s2.upload(hp)
+                ctx.msm_enqueue(k16.G1, d_bases, d_s2, n)
+                xh, _ = ctx.msm_finish(k16.G1)
+            dt = (time.perf_counter() - th0) / reps
+            ok = bool(k16.points_sum(k16.G1, np.frombuffer(xh, dtype=np.uint8).reshape(1, 128))[1] ==
+                      k16.points_sum(k16.G1, np.frombuffer(result, dtype=np.uint8).reshape(1, 128))[1]) if dist is None else None
+            host_leg = {"points_per_s": n / dt, "ms_per_msm": dt * 1e3, "calls": reps, "same_result_as_timed_region": ok,
+                        "note": "pinned host scalars uploaded (32 MB over PCIe) inside every call, one MSM at a time, result XYZZ on host"}
+            d_s2.free()
+        except Exception as e:   # a report, never the measured path
+            host_leg = {"error": repr(e)}
+
     # ---- the proof leg (every rank proves; rank 0 reports)
+    if c_exchange is not None:
+        c_exchange.close()      # (the communicator lives on this context, which the proof leg replaces)
+    if shards_obj is not None:
+        shards_obj.close()
     d_bases.free()
     d_scalars.free()
     proof = None
@@ -822,9 +949,17 @@ def main():
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tp) and not strong and args.log2n == 20:
             try:
-                traffic = json.load(open(tp)).get("msm_accumulate_hbm_bytes_per_launch")
-                traffic_src = "replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
-                              "command; not measured in this run)"
+                tj = json.load(open(tp))
+                # the counters were collected for ONE build of the kernel: the file carries a digest of the sources that
+                # make k_accumulate<Eng9>; a tree whose kernel sources differ reports no traffic figure instead of a stale one
+                if tj.get("kernel_sources_sha16") == kernel_sources_sha16():
+                    traffic = tj.get("msm_accumulate_hbm_bytes_per_launch")
+                    traffic_src = "replayed from profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                                  "command at commit %s, same kernel sources as this tree: digest %s; not measured in this run)" \
+                                  % (tj.get("commit"), tj.get("kernel_sources_sha16"))
+                else:
+                    traffic_src = "profiles/pmc_traffic.json was collected for other kernel sources (digest %s, this tree %s): " \
+                                  "no figure" % (tj.get("kernel_sources_sha16"), kernel_sources_sha16())
             except Exception:
                 traffic = None
         iso = iso_ms / max(iso_launches, 1)
@@ -837,6 +972,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "prewarm_steps": prewarm,
+            "value_driver_warmup_only": (warm_only or {}).get("value"),
+            "driver_warmup_only": warm_only,
             "cold": cold,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
@@ -851,11 +988,19 @@ def main():
                              % args.total_log2n) if strong else
                             ("BN254 G1 Pippenger MSM, 2^%d random scalars/points per GPU, result XYZZ on host" % args.log2n),
                 "points_per_gpu": n,
+                "scalars": "device-resident, the SAME array every step, its 32 MB H2D outside the timed region (kernel microbench; "
+                           "`host_scalars_leg` is the figure with pinned host scalars uploaded inside every step)",
                 "bases": "fixed-base window tables (k16_msm_fixed_base_prepare)" if fixed_tab is not None
                          else "prepared once (k16_msm_bases_prepare)" if prepared is not None
                          else "reference format (Montgomery affine), converted inside every step",
                 "sharding": ("contiguous shards (sharding.shard_range) + %s all_gather of 128-B partials + EC-add fold"
-                             % ("gloo (test rig: all ranks on GPU 0)" if SHARE_GPU else "RCCL")) if dist is not None else "single GPU",
+                             % ("gloo (test rig: all ranks on GPU 0)" if SHARE_GPU else
+                                "RCCL through libk16.so's k16_rank_comm_* (ncclAllGather)" if c_exchange is not None else
+                                "RCCL (torch.distributed)")) if dist is not None else
+                            ("single GPU" if shards_obj is None else
+                             "ONE process, %d shards (k16_msm_sharded_*: a context per shard on devices %s, host-side EC-add fold)"
+                             % (len(shard_devices), shard_devices)),
+                "exchange_note": c_exchange_note,
             },
             "roofline": {
                 "kernel": "k_accumulate<Eng9> (bucket accumulation, XYZZ mixed adds)",
@@ -889,6 +1034,7 @@ def main():
             },
             "stage_ms_isolated": stage_ms,
             "host_ms": host_ms,
+            "host_scalars_leg": host_leg,
             "proof": proof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -63,7 +63,12 @@ enum { K16_OP_ADD = 0, K16_OP_SUB, K16_OP_NEG, K16_OP_MUL, K16_OP_SQR, K16_OP_TO
         * multiplication that consumes them: (a + b) * b and (a - b) * b; K16_OP_BOUND_A counts in steps of 2 moduli here
         * (up to a + 30 p), b stays below 2 p as in the kernels */
        K16_OP_LAZY_ADDMUL, K16_OP_LAZY_SUBMUL };
-enum { K16_PT_ADD = 0, K16_PT_MADD, K16_PT_DBL };
+enum { K16_PT_ADD = 0, K16_PT_MADD, K16_PT_DBL,
+       /* K16_G1_ENG9 only: the bucket accumulation's own mixed addition (bn254_fq9.h acc9_madd: the accumulator keeps
+        * W = +-Y with a flag, the entry's sign goes into the addition, lazy subtractions).  p1 XYZZ, p2 affine as for
+        * K16_PT_MADD; K16_OP_BOUND_B bit 0: the entry is negative (result p1 - p2), bit 1: the accumulator arrives with
+        * W = -Y.  Result: the XYZZ representation of curve.cpp:185-250 for p1 + (+-p2). */
+       K16_PT_MADD_ACC };
 
 typedef struct k16_ctx    k16_ctx;
 typedef struct k16_prover k16_prover;
@@ -205,6 +210,48 @@ int  k16_msm_sort_from_lane(k16_ctx* ctx, int lane, int derive);
 int k16_msm_set_lane(k16_ctx* ctx, int lane);
 /* override the window size chosen for the next MSMs (0 = automatic) */
 int k16_msm_set_window_bits(k16_ctx* ctx, unsigned c);
+
+/* ---- ONE MSM sharded over several GPUs (BASELINE config 5: "MSMs above ~2^24 points shard the scalar / point
+ * array across the GPUs of a node") -- the multi-device form of Curve::multiMulByScalar -> ParallelMultiexp::multiexp
+ * (curve.hpp:209-215, multiexp.cpp:183-245).  Shard r owns the contiguous rows [lo_r, hi_r) (the first n % shards shards
+ * get one more row) of the point table and of the scalars; every shard runs the whole device pipeline on its rows; the only
+ * thing that leaves a device is the shard's partial result, ONE XYZZ point (128 / 256 B), and the results are folded with
+ * EC additions.
+ *
+ * (1) One process, several devices: one context per entry of `devices` (entries may repeat: two shards on one GPU is how
+ * one-GPU boxes test it).  The point table is placed once (static tables: k16_msm_sharded_set_bases* converts each slice to
+ * the kernels' row layout on its device); every run uploads / reads the scalars per shard on one host thread per shard and
+ * folds the partials on the host -- they arrive there anyway for the Horner combine, so no collective is needed.
+ * k16_msm_sharded_ctx gives the shard's context, e.g. to fill its slice with k16_synth_points. */
+typedef struct k16_msm_shards k16_msm_shards;
+int         k16_msm_sharded_create(const int* devices, int n_devices, int group, uint64_t n, k16_msm_shards** out);
+void        k16_msm_sharded_destroy(k16_msm_shards* s);
+int         k16_msm_sharded_count(const k16_msm_shards* s);
+int         k16_msm_sharded_range(const k16_msm_shards* s, int shard, uint64_t* lo, uint64_t* hi);
+k16_ctx*    k16_msm_sharded_ctx(k16_msm_shards* s, int shard);
+const char* k16_msm_sharded_last_error(const k16_msm_shards* s);
+/* h_bases: all n rows on the host, the reference's format (affine, Montgomery, LE) */
+int         k16_msm_sharded_set_bases(k16_msm_shards* s, const void* h_bases);
+/* ... or shard `shard`'s rows [lo, hi) already on that shard's device, same format */
+int         k16_msm_sharded_set_bases_device(k16_msm_shards* s, int shard, const void* d_slice);
+/* h_scalars: n x 32 B on the host (any 256-bit values).  Result as for k16_msm. */
+int         k16_msm_sharded_run(k16_msm_shards* s, const void* h_scalars, void* h_out_xyzz, void* h_out_affine);
+/* d_scalars[r]: shard r's (hi_r - lo_r) x 32 B already on shard r's device */
+int         k16_msm_sharded_run_device(k16_msm_shards* s, const void* const* d_scalars, void* h_out_xyzz, void* h_out_affine);
+/* wall time of the last run: all shards (upload + device work + per-shard combine, in parallel), the fold, the total */
+int         k16_msm_sharded_last_ms(const k16_msm_shards* s, double* shards_ms, double* fold_ms, double* total_ms);
+/* (2) One PROCESS per GPU (a launcher starts the ranks; each rank has its own context and its shard): the ranks exchange
+ * their partial results with ONE ncclAllGather over xGMI and every rank folds them in rank order (RCCL has no elliptic-curve
+ * reduction operator).  RCCL is dlopen'ed at the first call -- libk16.so does not link it; K16_ERR_NO_DEVICE (and
+ * k16_rank_comm_load_error) when it cannot be loaded.  Rank 0 makes the 128-byte id and hands it to all ranks by whatever
+ * the launcher offers (a file, MPI, a TCP store); k16_rank_comm_create is collective (ncclCommInitRank). */
+typedef struct k16_rank_comm k16_rank_comm;
+int         k16_rank_comm_unique_id(void* out128);
+const char* k16_rank_comm_load_error(void);
+int         k16_rank_comm_create(k16_ctx* ctx, int rank, int world, const void* unique_id128, k16_rank_comm** out);
+void        k16_rank_comm_destroy(k16_rank_comm* c);
+int         k16_rank_comm_allgather_fold(k16_rank_comm* c, int group, const void* h_partial_xyzz, void* h_out_xyzz,
+                                         void* h_out_affine);
 
 /* combine partial MSM results from several shards/GPUs: out = sum_i parts[i] (XYZZ, host) */
 int k16_points_sum(int group, const void* h_parts_xyzz, uint64_t count, void* h_out_xyzz, void* h_out_affine);

@@ -45,6 +45,14 @@ static constexpr uint32_t KP4[9] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b5
                              0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
 static constexpr uint32_t KP8[9] = {0x03e7ea38u, 0x082305b6u, 0x03951a78u, 0x16a91687u, 0x0c2ecbc0u,
                              0x16da0605u, 0x05370a08u, 0x12e131a0u, 0x01832273u};
+// 3p, 6p, 10p: offsets of the bucket accumulator's lazy subtractions (acc9_madd)
+static constexpr uint32_t KP3[9] = {0x0976f7d5u, 0x030d2224u, 0x1557e9edu, 0x087f6872u, 0x00918c68u,
+                             0x0891c242u, 0x01f4a3c3u, 0x0b14729cu, 0x00912cebu};
+static constexpr uint32_t KP6[9] = {0x12edefaau, 0x061a4448u, 0x0aafd3dau, 0x10fed0e5u, 0x012318d0u,
+                             0x11238484u, 0x03e94786u, 0x1628e538u, 0x012259d6u};
+static constexpr uint32_t KP10[9] = {0x14e1e4c6u, 0x0a2bc723u, 0x1c7a6116u, 0x1c535c28u, 0x173a7eb0u,
+                              0x1c908786u, 0x0684cc8au, 0x0f997e08u, 0x01e3eb10u};
+static constexpr uint32_t PINV = 0x1b799c77u; // p^-1 mod 2^29
 };
 // the same for the scalar field r (NTT chain): r in radix 2^29, -r^-1 mod 2^29, 2^261 / 2^266 / 2^256 mod r, k*r
 struct Fr9C {
@@ -89,6 +97,12 @@ K16_HD bool fq9_limbs_zero(const Fq9& a)
     return o == 0;
 }
 
+// K16_FMUL_CHAINS: accumulator chains per column of a product (2: the reduction terms run on a chain of their own and
+// are merged once per column -- half the dependent multiply-add depth, 17 more 64-bit additions per product; 1: one chain).
+#ifndef K16_FMUL_CHAINS
+#define K16_FMUL_CHAINS 2
+#endif
+
 // Montgomery product for radix 2^29: returns a*b/R' mod p, < p*(1 + A*B/169); limbs normalised.
 // Needs normalised inputs (l[0..7] < 2^29, l[8] < 2^29).  Product scanning; column k collects the
 // a_i*b_j with i+j = k and the m_i*p_j reduction terms; m_k clears the low 29 bits of column k.
@@ -100,17 +114,16 @@ K16_HD Fq9 fmul9_t(const Fq9& a, const Fq9& b)
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        uint64_t acc2 = 0; // second chain: halves the dependent-multiply-add depth per column
+        uint64_t  acc2 = 0; // second chain: halves the dependent-multiply-add depth per column
+        uint64_t& red  = K16_FMUL_CHAINS == 1 ? acc : acc2;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int j = k - i;
             if (j < 0 || j > 8) continue;
             acc += (uint64_t)a.l[i] * b.l[j];
-            if (i < k || k >= 9) {
-                if (i <= 8 && (k >= 9 || i < k)) acc2 += (uint64_t)m[i] * C::P[j];
-            }
+            if (k >= 9 || i < k) red += (uint64_t)m[i] * C::P[j];
         }
-        acc += acc2;
+        if (K16_FMUL_CHAINS != 1) acc += acc2;
         if (k < 9) {
             m[k] = ((uint32_t)acc * C::NP) & C::MASK;
             acc += (uint64_t)m[k] * C::P[0];
@@ -169,16 +182,17 @@ K16_HD Fq9 fsqr9_t(const Fq9& a)
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        uint64_t acc2 = 0;
+        uint64_t  acc2 = 0;
+        uint64_t& red  = K16_FMUL_CHAINS == 1 ? acc : acc2;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int j = k - i;
             if (j < 0 || j > 8) continue;
             if (i < j) acc += (uint64_t)a2[i] * a.l[j];
             if (i == j) acc += (uint64_t)a.l[i] * a.l[i];
-            if (k >= 9 || i < k) acc2 += (uint64_t)m[i] * C::P[j];
+            if (k >= 9 || i < k) red += (uint64_t)m[i] * C::P[j];
         }
-        acc += acc2;
+        if (K16_FMUL_CHAINS != 1) acc += acc2;
         if (k < 9) {
             m[k] = ((uint32_t)acc * C::NP) & C::MASK;
             acc += (uint64_t)m[k] * C::P[0];
@@ -202,16 +216,17 @@ K16_HD Fq9 fmul9_sum2_t(const Fq9& a, const Fq9& b, const Fq9& c, const Fq9& d)
     uint64_t acc = 0;
 #pragma unroll
     for (int k = 0; k < 17; k++) {
-        uint64_t acc2 = 0, acc3 = 0;
+        uint64_t  acc2 = 0, acc3 = 0;
+        uint64_t& red  = K16_FMUL_CHAINS == 1 ? acc3 : acc2; // one chain less: the reduction terms ride on the second product's
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int j = k - i;
             if (j < 0 || j > 8) continue;
             acc += (uint64_t)a.l[i] * b.l[j];
             acc3 += (uint64_t)c.l[i] * d.l[j];
-            if (k >= 9 || i < k) acc2 += (uint64_t)m[i] * C::P[j];
+            if (k >= 9 || i < k) red += (uint64_t)m[i] * C::P[j];
         }
-        acc += acc2 + acc3;
+        if (K16_FMUL_CHAINS != 1) acc += acc2 + acc3; else acc += acc3;
         if (k < 9) {
             m[k] = ((uint32_t)acc * C::NP) & C::MASK;
             acc += (uint64_t)m[k] * C::P[0];
@@ -299,16 +314,17 @@ K16_HD Fq9 fsub9_lazy4_t(const Fq9& a, const Fq9& b)
 // exact comparison with j*p, j = 0 .. J-1, for a normalised value < J*p:  V == 0 (mod p) ?
 // Prefilter on the low limb (false positives ~ J / 2^29), then a full 9-limb compare.
 template <int J>
+K16_HD bool fq9_maybe_zero_mod_p(const Fq9& a)
+{
+    return ((a.l[0] * Fq9C::PINV) & Fq9C::MASK) < (uint32_t)J;
+}
+template <int J>
 K16_HD bool fq9_is_zero_mod_p(const Fq9& a)
 {
     static_assert(J <= 12, "bound too large");
-    bool hit = false;
-    // j*p mod 2^29
-    constexpr uint32_t JP0[12] = {0x00000000u, 0x187cfd47u, 0x10f9fa8eu, 0x0976f7d5u, 0x01f3f51cu, 0x1a70f263u,
-                                  0x12edefaau, 0x0b6aecf1u, 0x03e7ea38u, 0x1c64e77fu, 0x14e1e4c6u, 0x0d5ee20du};
-#pragma unroll
-    for (int j = 0; j < J; j++) hit |= a.l[0] == JP0[j];
-    if (!hit) return false;
+    // prefilter: V = j*p has the low limb j*p mod 2^29, i.e. l[0] * p^-1 = j (mod 2^29) -- one multiplication instead of
+    // J comparisons (round 5)
+    if (((a.l[0] * Fq9C::PINV) & Fq9C::MASK) >= (uint32_t)J) return false;
     // slow path: subtract p until the value is below p (at most J-1 times), then test for zero
     Fq9 v = a;
     for (int j = 0; j < J; j++) {
@@ -398,6 +414,34 @@ K16_HD Fq9 finv9(const Fq9& a)
     return r;
 }
 
+// partial reduction (used by Fq2n / Fr9 below and by the rare branches of the G1 formulas)
+// v < 32p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17)):
+// v / 2^232 < (q + 1) * 3171407 and p / 2^232 > 3171406.3, so the remainder is below p (1 + (q + 1) * 2.2e-7) -- 7.1e-6 at
+// q = 31, against 2^-17 = 7.6e-6 (the NTT passes reduce tile values of up to 32 r with it); the reciprocal estimate is exact
+// or one less for top limbs below 2^27 (error t * 0.2 / 2^44 << 1), which the correction step settles.
+template <class C>
+K16_HD Fq9 fred9_t(const Fq9& v)
+{
+    const uint32_t t = v.l[8];
+    uint32_t       q = (uint32_t)(((uint64_t)t * 5547123ull) >> 44); // floor(t / 3171407) or one less
+    q += ((q + 1) * 3171407u <= t) ? 1u : 0u;
+    Fq9     r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        int64_t x = (int64_t)v.l[i] - (int64_t)((uint64_t)q * C::P[i]) + c;
+        if (i < 8) {
+            r.l[i] = (uint32_t)x & C::MASK;
+            c      = x >> 29;
+        } else {
+            r.l[8] = (uint32_t)x;
+        }
+    }
+    return r;
+}
+
+K16_HD Fq9 fred9(const Fq9& v) { return fred9_t<Fq9C>(v); }
+
 // ------------------------------------------------------------------------------------------------
 // G1 in XYZZ coordinates over Fq9.  Same formulas and the same exceptional-case order as
 // bn254_curve.h (curve.cpp:91-458 of the reference).  Invariant of every stored point:
@@ -465,6 +509,105 @@ K16_HD Xyzz9 padd_mixed9(const Xyzz9& p1, const Aff9& p2)
     Fq9 Y3  = fmul9_sum2(fsub9<8>(Q, X3), R, fsub9<4>(fq9_zero(), p1.y), PPP); // < 2
     return Xyzz9{X3, Y3, fmul9(p1.zz, PP), fmul9(p1.zzz, PPP)};
 }
+// ------------------------------------------------------------------------------------------------
+// The bucket accumulator of the hot loop (round 5: the mixed addition on an "instruction diet").
+// Same formulas, same branch order and the same (X, Y, ZZ, ZZZ) values as padd_mixed9 -- what changes is how the
+// subtractions are carried out:
+//   * the accumulator keeps W = +-Y with a flag (neg: W = -Y).  With R = S2 - Y1 and Y3 = R (Q - X3) - Y1 PPP:
+//       neg = 1:  T = S2 + W = R,    W' = T (Q - X3) + W PPP =  Y3  ->  neg' = 0
+//       neg = 0:  T = -S2 + W = -R,  W' = T (Q - X3) + W PPP = -Y3  ->  neg' = 1       (X3 = T^2 - PPP - 2Q either way)
+//     so no addition negates Y1 (fsub9<4>(0, Y1) before), R is a plain sum, and the sign moves to the gathered row's y,
+//     whose negation for the signed digits is there anyway: y is negated iff sign ^ neg ^ 1.
+//   * that negation is LAZY (3p - y limb by limb, 2^29 lent downwards: no carries) -- it feeds one multiplication;
+//   * X3 = T^2 + 6p - PPP - 2Q in ONE carry pass (three before), < 8p;
+//   * Q - X3 + 10p lazy (limbs < 3 * 2^29), the lazy operand of the two-product reduction (column bound 45 * 2^58);
+//   * the doubling test is a one-multiplication prefilter on P alone (P + (-P) needs no branch: the formulas give ZZ3 = 0).
+// Invariant: X < 8p, W < 4p, ZZ, ZZZ < 2p, all normalised.
+// ------------------------------------------------------------------------------------------------
+struct Acc9 {
+    Fq9      x, w, zz, zzz;
+    uint32_t neg; // 1: w = -Y
+    K16_HD bool is_zero() const { return fq9_is_zero_mod_p<2>(zz); }
+    static K16_HD Acc9 zero() { return Acc9{fq9_one(), fq9_one(), fq9_zero(), fq9_zero(), 0u}; }
+    static K16_HD Acc9 from_xyzz(const Xyzz9& p) { return Acc9{p.x, p.y, p.zz, p.zzz, 0u}; }
+    K16_HD Xyzz9 to_xyzz() const { return Xyzz9{x, neg ? fsub9<4>(fq9_zero(), w) : w, zz, zzz}; } // W < 4p -> Y <= 4p
+};
+// K*p with 2^29 lent to each of the limbs 0..7 by the limb above (the same integer): b normalised with b.l[8] < (K*p).l[8]
+// gives K*p - b limb by limb without a negative limb
+template <int K>
+K16_HD constexpr uint32_t fq9_lent_kp(int i)
+{
+    const uint32_t kp = K == 3 ? Fq9C::KP3[i] : (K == 10 ? Fq9C::KP10[i] : Fq9C::KP4[i]);
+    return i == 0 ? kp + (1u << 29) : (i < 8 ? kp + (1u << 29) - 1u : kp - 1u);
+}
+// rr + 6p - ppp - 2q, normalised: needs ppp + 2q <= 6p; result < RR + 6
+K16_HD Fq9 fq9_x3(const Fq9& rr, const Fq9& ppp, const Fq9& q)
+{
+    Fq9     r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        int32_t t = (int32_t)(rr.l[i] + Fq9C::KP6[i]) - (int32_t)(ppp.l[i] + 2u * q.l[i]) + c;
+        if (i < 8) {
+            r.l[i] = (uint32_t)t & Fq9C::MASK;
+            c      = t >> 29;
+        } else {
+            r.l[8] = (uint32_t)t;
+        }
+    }
+    return r;
+}
+#ifndef K16_FQ9_HOOK
+#define K16_FQ9_HOOK(what, v) // tests/cpp/fq9_check.cpp looks at the intermediate values through this
+#endif
+// acc += (sign ? -row : row); row as it lies in the table (x, y < 2p, normalised; (0,0) = the point at infinity)
+K16_HD void acc9_madd(Acc9& a, const Aff9& row, uint32_t sign)
+{
+    if (row.is_zero()) return;
+    const bool negy = ((sign ^ a.neg ^ 1u) & 1u) != 0;
+    Fq9        ym; // +-y, lazy: limbs < 2^30, value <= 3p
+#pragma unroll
+    for (int i = 0; i < 9; i++) ym.l[i] = negy ? fq9_lent_kp<3>(i) - row.y.l[i] : row.y.l[i];
+    K16_FQ9_HOOK("ym", ym);
+    if (a.is_zero()) { // infinity + row
+        a.x   = row.x;
+        a.w   = fadd9(ym, fq9_zero()); // normalise
+        a.zz  = fq9_one();
+        a.zzz = fq9_one();
+        a.neg ^= 1u;
+        return;
+    }
+    Fq9 U2 = fmul9(row.x, a.zz);                     // 2*2 -> 2
+    Fq9 S  = fmul9(ym, a.zzz);                       // 3*2 -> 2
+    Fq9 P  = fsub9<8>(U2, a.x);                      // X1 < 8 -> P < 10
+    Fq9 T  = fadd9(S, a.w);                          // W < 4 -> T < 6
+    if (fq9_maybe_zero_mod_p<10>(P)) {
+        if (fq9_is_zero_mod_p<10>(P) && fq9_is_zero_mod_p<6>(T)) { // acc == +-row with the same sign: doubling
+            // the signed row's y from ym (row.y itself is dead by now: nine registers less across the products above):
+            // ym = +-y_e with the sign negy ^ sign, <= 3p; fred9 brings it below 2p for the doubling's bounds
+            const Fq9 yn = fadd9(ym, fq9_zero());
+            Xyzz9     d  = pdbl_aff9(Aff9{row.x, fred9(negy == ((sign & 1u) != 0) ? yn : fsub9<4>(fq9_zero(), yn))});
+            a            = Acc9::from_xyzz(d);
+            return;
+        }
+    }
+    Fq9 PP  = fsqr9(P);                              // 100 -> 2
+    Fq9 RR  = fsqr9(T);                              // 36 -> 2
+    Fq9 PPP = fmul9(P, PP);                          // 20 -> 2
+    Fq9 Q   = fmul9(a.x, PP);                        // 16 -> 2
+    Fq9 X3  = fq9_x3(RR, PPP, Q);                    // < 8
+    Fq9 D;                                           // Q - X3 + 10p, lazy: limbs < 3 * 2^29, value < 12p
+#pragma unroll
+    for (int i = 0; i < 9; i++) D.l[i] = Q.l[i] + fq9_lent_kp<10>(i) - X3.l[i];
+    K16_FQ9_HOOK("D", D);
+    Fq9 W3 = fmul9_sum2(D, T, a.w, PPP);             // 12*6 + 4*2 = 80 -> 2
+    a.zz   = fmul9(a.zz, PP);
+    a.zzz  = fmul9(a.zzz, PPP);
+    a.x    = X3;
+    a.w    = W3;
+    a.neg ^= 1u;
+}
+
 // affine + affine -> XYZZ: the mixed addition above with ZZ1 = ZZZ1 = 1 (U2 = x2, S2 = y2, ZZ3 = PP, ZZZ3 = PPP), i.e.
 // the same values as padd_mixed9(from_aff(a), b) for 4 multiplications less.  First add of every bucket segment.
 K16_HD Xyzz9 padd_aff_aff9(const Aff9& a, const Aff9& b)
@@ -524,32 +667,6 @@ K16_HD Xyzz9 xyzz9_from_canonical(const Xyzz<Fq>& p)
 // (value / 2^232 against p / 2^232 = 3171406.3): one 9-limb multiply-subtract, ~15 % of a multiply.
 // With the invariant in place the generic XYZZ formulas of bn254_curve.h apply unchanged (G2).
 // ------------------------------------------------------------------------------------------------
-// v < 32p, normalised  ->  v - q*p with q = floor(v.l[8] / 3171407)  in [0, p * (1 + 2^-17)):
-// v / 2^232 < (q + 1) * 3171407 and p / 2^232 > 3171406.3, so the remainder is below p (1 + (q + 1) * 2.2e-7) -- 7.1e-6 at
-// q = 31, against 2^-17 = 7.6e-6 (the NTT passes reduce tile values of up to 32 r with it); the reciprocal estimate is exact
-// or one less for top limbs below 2^27 (error t * 0.2 / 2^44 << 1), which the correction step settles.
-template <class C>
-K16_HD Fq9 fred9_t(const Fq9& v)
-{
-    const uint32_t t = v.l[8];
-    uint32_t       q = (uint32_t)(((uint64_t)t * 5547123ull) >> 44); // floor(t / 3171407) or one less
-    q += ((q + 1) * 3171407u <= t) ? 1u : 0u;
-    Fq9     r;
-    int64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        int64_t x = (int64_t)v.l[i] - (int64_t)((uint64_t)q * C::P[i]) + c;
-        if (i < 8) {
-            r.l[i] = (uint32_t)x & C::MASK;
-            c      = x >> 29;
-        } else {
-            r.l[8] = (uint32_t)x;
-        }
-    }
-    return r;
-}
-
-K16_HD Fq9 fred9(const Fq9& v) { return fred9_t<Fq9C>(v); }
 
 struct Fq2n {
     Fq9 a, b;

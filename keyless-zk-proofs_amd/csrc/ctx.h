@@ -38,8 +38,28 @@ struct k16_ntt_table {
     k16::Fq9  pow2inv9[34];     // 2^-k as Fr9
 };
 
+// Every environment switch of the library, read ONCE when a context is created (k16_ctx_create) and
+// kept in the context: no getenv on any per-MSM, per-transform or per-proof path (getenv races with a host program's setenv
+// and costs a lock per call), and an object made from a context (prover, verifying key) sees the values its context was made
+// with.  All of these select between code paths that give the SAME results (alternative / reference implementations kept
+// parity-tested, rejected scheduling experiments kept so that they can be re-measured) or switch diagnostics on.  Switches
+// that change a RESULT on purpose (measurement probes, fault injection) do not exist in libk16.so: they are compiled only
+// into the lab / testing builds (-DK16_LAB, -DK16_TESTING).
+struct k16_tuning {
+    bool     atomic_sort = false, no_fused_convert = false, no_staged_sort = false, fused_bins = false, x8 = false;
+    bool     no_l1_prefetch = false, ntt_tail_small = false, ntt_unfused = false;
+    bool     no_fixed_base = false, no_stream_priority = false, b_sort = false, b_derive = false, no_skip_zero_rows = false;
+    bool     classes = false, no_warmup = false, spmv_full = false, fused_hscalars = false, no_split_classes = false;
+    bool     b2_first = false, no_acc_skip = false;
+    bool     trace = false, trace_enq = false, trace_host = false, verify_no_coop = false, verify_coop_trace = false;
+    int      seg = 0, wsum_mlog = -1, witness_c = 0, ntt_tile_log = 0, narrow_chain = 0, narrow_chain_g2 = 0;
+    uint64_t verify_coop_max = 2048;
+    static k16_tuning from_env();
+};
+
 struct k16_ctx {
     int         device = 0;
+    k16_tuning  tune;
     hipStream_t stream = nullptr;
     hipEvent_t  ev_a = nullptr, ev_b = nullptr;     // k16_timer_*
     // kernel stats: event pairs are recorded without synchronising; resolved in k16_kernel_stats_get
@@ -103,6 +123,7 @@ struct k16_ctx {
         // below 2^narrow with bit b set) at NARROW_OFF; the result is the windows' value + sum_b 2^b S_b
         unsigned narrow = 0;
         const struct k16_scalar_classes* cls = nullptr;
+        bool     cls_overflow = false; // the classes object went away before the finish: its overflow flag, copied (k16_scalar_classes_destroy)
     };
     static constexpr size_t NARROW_OFF = SLOT_BYTES - 4096; // 8 points of <= 288 bytes at the end of a staging slot
     // One thread may enqueue while another finishes (bench.py does: launches on a slow host then overlap the wait for the

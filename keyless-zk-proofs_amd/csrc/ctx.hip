@@ -51,6 +51,47 @@ extern "C" int k16_device_count(void)
     return n < 0 ? 0 : n;
 }
 
+k16_tuning k16_tuning::from_env()
+{
+    k16_tuning t;
+    auto on  = [](const char* n) { return getenv(n) != nullptr; };
+    auto onv = [](const char* n) { const char* e = getenv(n); return e && atoi(e) != 0; };
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    t.atomic_sort        = on("K16_ATOMIC_SORT");
+    t.no_fused_convert   = on("K16_NO_FUSED_CONVERT");
+    t.no_staged_sort     = on("K16_NO_STAGED_SORT");
+    t.fused_bins         = on("K16_FUSED_BINS");
+    t.x8                 = on("K16_X8");
+    t.no_l1_prefetch     = on("K16_NO_L1_PREFETCH");
+    t.ntt_tail_small     = on("K16_NTT_TAIL_SMALL");
+    t.ntt_unfused        = on("K16_NTT_UNFUSED");
+    t.no_fixed_base      = on("K16_NO_FIXED_BASE");
+    t.no_stream_priority = on("K16_NO_STREAM_PRIORITY");
+    t.b_sort             = onv("K16_B_SORT");
+    t.b_derive           = onv("K16_B_DERIVE");
+    t.no_skip_zero_rows  = on("K16_NO_SKIP_ZERO_ROWS");
+    t.classes            = onv("K16_CLASSES");
+    t.no_warmup          = on("K16_NO_WARMUP");
+    t.spmv_full          = on("K16_SPMV_FULL");
+    t.fused_hscalars     = on("K16_FUSED_HSCALARS");
+    t.no_split_classes   = on("K16_NO_SPLIT_CLASSES");
+    t.b2_first           = on("K16_B2_FIRST");
+    t.no_acc_skip        = on("K16_NO_ACC_SKIP");
+    t.trace              = on("K16_TRACE");
+    t.trace_enq          = on("K16_TRACE_ENQ");
+    t.trace_host         = on("K16_TRACE_HOST");
+    t.verify_no_coop     = on("K16_VERIFY_NO_COOP");
+    t.verify_coop_trace  = on("K16_VERIFY_COOP_TRACE");
+    t.seg                = num("K16_SEG", 0);
+    t.wsum_mlog          = num("K16_WSUM_MLOG", -1);
+    t.witness_c          = num("K16_WITNESS_C", 0);
+    t.ntt_tile_log       = num("K16_NTT_TILE_LOG", 0);
+    t.narrow_chain       = num("K16_NARROW_CHAIN", 0);
+    t.narrow_chain_g2    = num("K16_NARROW_CHAIN_G2", 0);
+    if (const char* e = getenv("K16_VERIFY_COOP_MAX")) t.verify_coop_max = strtoull(e, nullptr, 10);
+    return t;
+}
+
 extern "C" int k16_ctx_create(int device, k16_ctx** out)
 {
     return k16_guard(nullptr, [&]() -> int {
@@ -61,6 +102,7 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     if (hipSetDevice(device) != hipSuccess) return K16_ERR_NO_DEVICE;
     k16_ctx* c = new k16_ctx();
     c->device  = device;
+    c->tune    = k16_tuning::from_env(); // the only place the library reads its tuning switches
     bool lanes_ok = true;
     for (int i = 0; i < k16_ctx::N_LANES; i++)
         lanes_ok = lanes_ok && (i > 0 || hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess) &&
@@ -495,6 +537,17 @@ __global__ void k_point_op_eng9(int op, unsigned ka, unsigned kb, const G1Xyzz* 
     case K16_PT_ADD: z = padd9(a, in9(((const G1Xyzz*)p2)[i], kb)); break;
     case K16_PT_MADD: z = padd_mixed9(a, aff9_from_canonical(((const G1Aff*)p2)[i])); break;
     case K16_PT_DBL: z = pdbl9(a); break;
+    case K16_PT_MADD_ACC: {
+        // the bucket accumulation's own addition (acc9_madd): kb bit 0 = the entry's sign (the row is subtracted), kb bit 1 =
+        // the accumulator arrives with W = -Y
+        Acc9 acc = Acc9::from_xyzz(a);
+        if (kb & 2u) {
+            acc.w   = fsub9<4>(fq9_zero(), a.y);
+            acc.neg = 1u;
+        }
+        acc9_madd(acc, aff9_from_canonical(((const G1Aff*)p2)[i]), kb & 1u);
+        z = acc.to_xyzz();
+    } break;
     default: z = Xyzz9::zero();
     }
     r[i] = G1Xyzz{fq9_to_fq(z.x), fq9_to_fq(z.y), fq9_to_fq(z.zz), fq9_to_fq(z.zzz)}; // coordinate by coordinate
@@ -673,13 +726,17 @@ extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1,
     if (!c || !h_p1 || !h_r || group < K16_G1 || group > K16_G2_ENG2N) return K16_ERR_ARG;
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
-    if ((ka || kb) && (group != K16_G1_ENG9 || ka > 2 || kb > 2 || (kb && op != K16_PT_ADD))) return K16_ERR_ARG;
+    if (op == K16_PT_MADD_ACC) {
+        if (group != K16_G1_ENG9 || ka > 2 || kb > 3) return K16_ERR_ARG;
+    } else if ((ka || kb) && (group != K16_G1_ENG9 || ka > 2 || kb > 2 || (kb && op != K16_PT_ADD)))
+        return K16_ERR_ARG;
+    if (op < K16_PT_ADD || op > K16_PT_MADD_ACC) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(c, hipSetDevice(c->device));
     const bool g1 = group == K16_G1 || group == K16_G1_ENG9;
     size_t xb  = g1 ? sizeof(G1Xyzz) : sizeof(G2Xyzz);
     size_t ab  = g1 ? sizeof(G1Aff) : sizeof(G2Aff);
-    size_t p2b = (op == K16_PT_MADD) ? ab : xb;
+    size_t p2b = (op == K16_PT_MADD || op == K16_PT_MADD_ACC) ? ab : xb;
     void * d1 = nullptr, *d2 = nullptr, *dr = nullptr;
     K16_HIP(c, hipMalloc(&d1, n * xb));
     K16_HIP(c, hipMalloc(&dr, n * xb));

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/k16.h"
+#include <time.h>
 #include "../../include/k16_fullprover.hpp"
 
 namespace {
@@ -23,8 +24,17 @@ bool log_on()
 void log_line(const char* level, const char* msg)
 {
     if (!log_on()) return;
-    // same shape as the reference's log() (fullprover.cpp:67-78)
-    printf("{\"level\":\"%s\",\"message\":\"%s\",\"native_code\":\"1\",\"target\":\"prover_service::k16\"}\n", level, msg);
+    // same fields as the reference's log() (fullprover.cpp:41-78): UTC timestamp with milliseconds, level, message,
+    // native_code, target -- as VALID JSON (the reference's line carries a stray quote after "native_code":"1")
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    struct tm tmv;
+    gmtime_r(&ts.tv_sec, &tmv);
+    char stamp[40];
+    const size_t k = strftime(stamp, sizeof stamp, "%Y-%m-%dT%H:%M:%S", &tmv);
+    snprintf(stamp + k, sizeof stamp - k, ".%03ldZ", ts.tv_nsec / 1000000L);
+    printf("{\"timestamp\":\"%s\",\"level\":\"%s\",\"message\":\"%s\",\"native_code\":\"1\",\"target\":\"prover_service::k16\"}\n",
+           stamp, level, msg);
     fflush(stdout);
 }
 

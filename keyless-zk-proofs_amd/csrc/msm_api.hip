@@ -137,6 +137,26 @@ extern "C" int k16_msm_fixed_base_info(uint64_t n, unsigned* c_out, uint64_t* ta
     });
 }
 
+// The one-shot requests of the NEXT enqueue (zero-row mask, accumulation mask, row indirection, sort reuse / derive, scalars
+// still to be formed) cover exactly one enqueue -- also one that returns early: n == 0, a full result ring, n too large, any
+// error before msm_enqueue_t has consumed them (they then applied to the next, unrelated MSM, whose rows were
+// silently dropped).  Cleared on every way out.
+struct OneShotGuard {
+    k16_ctx* c;
+    explicit OneShotGuard(k16_ctx* cx) : c(cx) {}
+    ~OneShotGuard()
+    {
+        if (!c) return;
+        c->skip_next       = nullptr;
+        c->acc_skip_next   = nullptr;
+        c->remap_next      = nullptr;
+        c->derive_lane     = -1;
+        c->reuse_sort      = false;
+        c->reuse_sort_lane = -1;
+        c->hs_next[0] = c->hs_next[1] = c->hs_next[2] = nullptr;
+    }
+};
+
 extern "C" int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d_bases, uint64_t n, void* d_table)
 {
     return k16_guard(ctx, [&]() -> int {
@@ -153,6 +173,7 @@ extern "C" int k16_msm_fixed_base_prepare(k16_ctx* ctx, int group, const void* d
 extern "C" int k16_msm_enqueue_fixed_base(k16_ctx* ctx, int group, const void* d_table, const void* d_scalars, uint64_t n)
 {
     return k16_guard(ctx, [&]() -> int {
+    OneShotGuard one_shot(ctx);
     if (!ctx || group != K16_G1 || !d_table || !d_scalars) return K16_ERR_ARG;
     const unsigned c = fixed_base_c(n);
     if (!c) {
@@ -268,6 +289,7 @@ struct HostTimer {
 
 static int msm_enqueue_any(k16_ctx* ctx, int group, const void* d_bases, const void* d_scalars, uint64_t n, int prepared)
 {
+    OneShotGuard one_shot(ctx);
     if (!ctx || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
     HostTimer ht(ctx, "host_enqueue");
     K16_HIP(ctx, hipSetDevice(ctx->device)); // the calling thread may be new (bench.py enqueues from a second thread)
@@ -328,6 +350,7 @@ extern "C" int k16_msm_enqueue_prepared(k16_ctx* ctx, int group, const void* d_p
 // then phase 2 (wide part, the MSM joins the result queue) in the same order.
 int k16_msm_classified_phase(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set, int phase)
 {
+    OneShotGuard one_shot(ctx);
     if (!ctx || !cls || cls->ctx != ctx || (group != K16_G1 && group != K16_G2) || set < 0 || set >= cls->n_sets ||
         (cls->n && !d_prepared))
         return K16_ERR_ARG;
@@ -451,7 +474,7 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
     HostTimer hc(ctx, "host_finish_combine");
     const char*    src = (const char*)ctx->pinned + (size_t)pd.slot * k16_ctx::SLOT_BYTES;
     const unsigned cnt = pd.w * (pd.nbits + 2);
-    if (pd.cls && pd.cls->h_flags[0]) { // the classification met more wide scalars than its caller announced: some were dropped
+    if (pd.cls_overflow || (pd.cls && pd.cls->h_flags[0])) { // the classification met more wide scalars than its caller announced: some were dropped
         pop();
         ctx->err = "k16_msm_finish: the scalar classes were built with a wide-scalar bound below the actual count";
         return K16_ERR_ARG;

@@ -199,6 +199,16 @@ extern "C" void k16_scalar_classes_destroy(k16_scalar_classes* c)
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
     (void)hipDeviceSynchronize();
+    // MSMs still waiting for their k16_msm_finish keep a pointer to this object for its overflow flag (written by the
+    // device, final after the synchronisation above): hand them the flag's value instead (use-after-free)
+    {
+        std::lock_guard<std::mutex> lk(c->ctx->ring_mu);
+        for (auto& pd : c->ctx->pend)
+            if (pd.cls == c) {
+                pd.cls_overflow = c->h_flags && c->h_flags[0] != 0;
+                pd.cls          = nullptr;
+            }
+    }
     classes_free(c);
     });
 }

@@ -1,4 +1,7 @@
 // msm_g1.hip -- G1 instantiation of the MSM kernels, on the radix-2^29 engine (bn254_fq9.h)
+// one accumulator chain per product column in the G1 kernels (bn254_fq9.h K16_FMUL_CHAINS): 153 fewer 64-bit additions per mixed
+// addition, 1 % on the bucket accumulation (round 5, profiles/r05/ab_accumulate_formulas.log); the NTT and G2 units keep two
+#define K16_FMUL_CHAINS 1
 #include <algorithm>
 #include "msm_kernels.inc"
 
@@ -23,8 +26,8 @@ int k16_msm_enqueue_g1(k16_ctx* ctx, const void* d_bases, const void* d_scalars,
         rows = (const k16::G1Aff*)L.ws_conv.p;
         // the conversion rides in the sort's counting pass when there is one (LDS partition sort, no reused sort, no
         // captured graphs -- a graph would pin this call's table pointer); otherwise it is a kernel of its own
-        const bool fuse = n <= (1u << 24) && !ctx->reuse_sort && ctx->derive_lane < 0 && !ctx->graphs_on && getenv("K16_ATOMIC_SORT") == nullptr &&
-                          getenv("K16_NO_FUSED_CONVERT") == nullptr;
+        const bool fuse = n <= (1u << 24) && !ctx->reuse_sort && ctx->derive_lane < 0 && !ctx->graphs_on && !ctx->tune.atomic_sort &&
+                          !ctx->tune.no_fused_convert;
         if (ctx->lean_sort) {
             // lean sort: the counting pass stays at 25 VGPRs (the fused conversion made it 82), and the conversion is the
             // 5-doubling kernel -- both fit beside another lane's bucket accumulation

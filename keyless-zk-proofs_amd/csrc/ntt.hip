@@ -370,8 +370,7 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
     // whatever the layout between the passes).  Measured in a proof (three polynomials per launch, 2^21, round 4): forward
     // 395 + 684 us against 610 + 349 + 300, the inverse with its TAIL store 372 + 1194 against 309 + 393 + 450; proof p50
     // 6.03-6.18 (both), 5.85-6.06 (forward only) against 5.86-6.05 ms: no gain, so 1024 stays the default.
-    static const bool tail_small = getenv("K16_NTT_TAIL_SMALL") != nullptr;
-    if (tail_dst && tail_small) tile_log = 10;
+    if (tail_dst && ctx->tune.ntt_tail_small) tile_log = 10;
     const uint32_t TLMAX = tile_log == 11 ? 1u : 4u;
     while (s0 < logn) {
         const uint32_t TL = s0 < TLMAX ? s0 : TLMAX;                    // T = min(2^s0, 16) lo values per tile
@@ -439,16 +438,13 @@ int k16_ntt_enqueue(k16_ctx* ctx, k16::Fr* d_a, uint64_t n, k16_ntt_table* tab, 
     packed9 &= 1;
     if (logn >= 1) {
         if (!skip_bitrev) hipLaunchKernelGGL(k_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, logn);
-        if (!packed9 && getenv("K16_NTT_UNFUSED")) {
+        if (!packed9 && ctx->tune.ntt_unfused) {
             for (uint32_t s = 1; s <= logn; s++)
                 hipLaunchKernelGGL(k_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, d_a, tab->roots, logn,
                                    s, tab->s);
         } else {
             Fr* one[1] = {d_a};
-            static const uint32_t pub_tile = [] {
-                const char* e = getenv("K16_NTT_TILE_LOG");
-                return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 10u;
-            }();
+            const uint32_t pub_tile = ctx->tune.ntt_tile_log ? (uint32_t)std::max(10, std::min(11, ctx->tune.ntt_tile_log)) : 10u;
             ntt_passes(ctx, one, 1, logn, tab, packed9 != 0, nullptr, nullptr, st, logn >= 12 ? pub_tile : 10u);
         }
     }
@@ -484,10 +480,7 @@ int k16_ntt_coset_chain(k16_ctx* ctx, k16::Fr* const* src, k16::Fr* const* dst, 
         return K16_OK;
     }
     k16_stat_scope ss(ctx, "ntt", st);
-    static const uint32_t fwd_tile = [] {
-        const char* e = getenv("K16_NTT_TILE_LOG");
-        return e ? (uint32_t)std::max(10, std::min(11, atoi(e))) : 10u;
-    }();
+    const uint32_t fwd_tile = ctx->tune.ntt_tile_log ? (uint32_t)std::max(10, std::min(11, ctx->tune.ntt_tile_log)) : 10u;
     ntt_passes(ctx, src, count, logn, tab, true, dst, shift9, st, logn >= 12 ? fwd_tile : 10u);
     ntt_passes(ctx, dst, count, logn, tab, true, nullptr, nullptr, st, logn >= 12 ? fwd_tile : 10u);
     K16_HIP(ctx, hipGetLastError());

@@ -12,6 +12,8 @@
 // on the device; the O(1) blinding arithmetic (groth16.cpp:325-352), the affine conversion and
 // the decimal JSON stay on the host, using the same field code (bn254_field.h) compiled for x86.
 #include <fcntl.h>
+#include <sys/random.h>
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -285,21 +287,50 @@ bool geq_r(const uint8_t v[32])
     }
     return true;
 }
-// groth16.cpp:296-316 : 32 random bytes, top two bits cleared, rejected while >= r
+// groth16.cpp:296-316 + random_generator.hpp:4-25 : 32 random bytes, top two bits cleared, rejected while >= r.  The bytes
+// come from getrandom(2) (the kernel's CSPRNG, no file descriptor, no failure once the pool is initialised); a short or
+// interrupted read is retried, and only a kernel without the system call falls back to /dev/urandom.
+static bool random_bytes(uint8_t* out, size_t n)
+{
+    size_t got = 0;
+    while (got < n) {
+        const ssize_t r = ::getrandom(out + got, n - got, 0);
+        if (r > 0) {
+            got += (size_t)r;
+            continue;
+        }
+        if (r < 0 && (errno == EINTR || errno == EAGAIN)) continue;
+        break; // ENOSYS and the like
+    }
+    if (got == n) return true;
+    int fd = ::open("/dev/urandom", O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    while (got < n) {
+        const ssize_t r = ::read(fd, out + got, n - got);
+        if (r > 0) {
+            got += (size_t)r;
+            continue;
+        }
+        if (r < 0 && errno == EINTR) continue;
+        break;
+    }
+    ::close(fd);
+    return got == n;
+}
 int sample_blinding(uint8_t out[32])
 {
-    int fd = ::open("/dev/urandom", O_RDONLY);
-    if (fd < 0) return K16_ERR_IO;
     do {
-        if (::read(fd, out, 32) != 32) {
-            ::close(fd);
-            return K16_ERR_IO;
-        }
+        if (!random_bytes(out, 32)) return K16_ERR_IO;
         out[31] &= 0x3f;
     } while (geq_r(out));
-    ::close(fd);
     return K16_OK;
 }
+// the blinding scalars (and values derived from them) do not outlive the proof: wiped on every way out of the function
+struct WipeOnExit {
+    void*  p;
+    size_t n;
+    ~WipeOnExit() { explicit_bzero(p, n); }
+};
 
 int msm_prepared(k16_ctx* ctx, int group, const void* d_rows, const void* d_scalars, uint64_t n, void* out_xyzz)
 {
@@ -654,7 +685,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         unsigned fc   = 0;
         uint64_t rows = 0;
         k16_msm_fixed_base_info(N, &fc, &rows);
-        if (fc && !getenv("K16_NO_FIXED_BASE")) {
+        if (fc && !ctx->tune.no_fixed_base) {
             K16_HIP_P(ctx, hipMalloc((void**)&p->d_Htab, (size_t)rows * 64), p);
             if ((rc = k16_msm_fixed_base_prepare(ctx, K16_G1, p->d_H, N, p->d_Htab))) {
                 prover_free(p);
@@ -685,7 +716,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         // that its kernels are not queued behind the witness MSMs that run beside it
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (getenv("K16_NO_STREAM_PRIORITY")) greatest = 0;
+        if (ctx->tune.no_stream_priority) greatest = 0;
         K16_HIP_P(ctx, hipStreamCreateWithPriority(&p->st2, hipStreamNonBlocking, greatest), p);
     }
     K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_w, hipEventDisableTiming), p);
@@ -724,7 +755,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         // against 6.00-6.02 ms, but four provers sharing the GPU 161-163 against 165-168 proofs/s (the sort is memory
         // traffic on top of what the other provers' sorts already move; the additions it saves were issue slots nobody was
         // short of there) -- profiles/r04/ab_b_sort.log.  Off by default.
-        p->b_sort = getenv("K16_B_SORT") && atoi(getenv("K16_B_SORT")) != 0 && p->n_vars >= (1u << 17) && n_b >= p->n_vars / 8;
+        p->b_sort = ctx->tune.b_sort && p->n_vars >= (1u << 17) && n_b >= p->n_vars / 8;
         if (!p->b_sort)
             for (size_t k = 0; k < mw; k++) ac[k] &= bb[k];
         // K16_B_DERIVE=1: the one partition (A's) serves every table, and B1 / B2 -- when an eighth or more of the wires are
@@ -733,14 +764,14 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         // (they read A's lists and step over their (0,0) rows in the accumulation, k_accumulate_skip): B2's accumulation
         // 1.06 -> 0.65 ms, p50 the same (5.78-5.98 both), four provers 167 against 171-179 proofs/s -- as with K16_B_SORT the
         // additions saved were not what the proof waits for, and the extra launches cost the other provers; off.
-        p->b_derive = !p->b_sort && getenv("K16_B_DERIVE") && atoi(getenv("K16_B_DERIVE")) != 0 && p->n_vars >= (1u << 17) &&
+        p->b_derive = !p->b_sort && ctx->tune.b_derive && p->n_vars >= (1u << 17) &&
                       n_b >= p->n_vars / 8;
         K16_HIP_P(ctx, hipMalloc(&p->d_skip_ac, mb), p);
         K16_HIP_P(ctx, hipMalloc(&p->d_skip_b, mb), p);
         K16_HIP_P(ctx, hipMemcpyAsync(p->d_skip_ac, ac.data(), mb, hipMemcpyHostToDevice, st), p);
         K16_HIP_P(ctx, hipMemcpyAsync(p->d_skip_b, bb.data(), mb, hipMemcpyHostToDevice, st), p);
         K16_HIP_P(ctx, hipStreamSynchronize(st), p);
-        if (getenv("K16_NO_SKIP_ZERO_ROWS")) {
+        if (ctx->tune.no_skip_zero_rows) {
             (void)hipFree(p->d_skip_ac);
             (void)hipFree(p->d_skip_b);
             p->d_skip_ac = p->d_skip_b = nullptr;
@@ -753,7 +784,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
         // non-zero digit either way -- and the bucket path, whose kernels start before the NTT passes fill the chip, ends its
         // G2 MSM earlier: p50 5.95-6.03 against 6.06-6.08 ms, four provers 173-177 against 161-165 proofs/s, same box,
         // profiles/r04/ab_witness_classes.log.)
-        if (getenv("K16_CLASSES") && atoi(getenv("K16_CLASSES")) != 0) {
+        if (ctx->tune.classes) {
             for (int t = 0; t < 4; t++) {
                 int sidx = -1;
                 for (int u = 0; u < t && sidx < 0; u++)
@@ -775,7 +806,7 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
 #else
     const bool fault_env = false;
 #endif
-    if (!getenv("K16_NO_WARMUP") && !fault_env) {
+    if (!ctx->tune.no_warmup && !fault_env) {
         std::vector<uint8_t> w((size_t)p->n_vars * 32, 0);
         w[0] = 1;
         uint8_t one[32] = {1};
@@ -905,8 +936,9 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         ctx->err = "witness has fewer values than the circuit has wires";
         return K16_ERR_FORMAT;
     }
-    uint8_t r_std[32], s_std[32];
-    int     rc;
+    uint8_t    r_std[32], s_std[32];
+    WipeOnExit wipe_r{r_std, 32}, wipe_s{s_std, 32};
+    int        rc;
     if (r_in) {
         memcpy(r_std, r_in, 32);
     } else if ((rc = sample_blinding(r_std))) {
@@ -925,7 +957,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     K16_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t    st = ctx->stream;
     const uint32_t N  = p->domain_size;
-    static const bool host_trace = getenv("K16_TRACE_HOST") != nullptr;
+    const bool        host_trace = ctx->tune.trace_host;
     const auto        ht0 = std::chrono::steady_clock::now();
     auto              ht  = [&](const char* what) {
         if (host_trace)
@@ -968,7 +1000,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     K16_HIP(ctx, hipEventRecord(p->ev_w, st));
     K16_HIP(ctx, hipStreamWaitEvent(s2, p->ev_w, 0));
     const unsigned gN = (N + 255) / 256;
-    static const bool spmv_n16 = getenv("K16_SPMV_FULL") == nullptr;
+    const bool spmv_n16 = !ctx->tune.spmv_full;
     {
         const uint64_t waves = (uint64_t)p->n_slices + p->n_long;
         if (waves)
@@ -986,7 +1018,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     // (K16_FUSED_HSCALARS=1; measured: the counting pass grows from 40 to 97 us, the 53 us kernel and its gap disappear -- 4 us
     // less between the chain's end and the end of the counting pass, profiles/r04/proof_timeline_fused_h_scalars.txt: the
     // scalars' arithmetic, 46 us of multiply issue, moves with them; off)
-    static const bool hs_fuse = getenv("K16_FUSED_HSCALARS") != nullptr;
+    const bool        hs_fuse = ctx->tune.fused_hscalars;
     const bool        hs_in_sort = hs_fuse && p->d_Htab != nullptr;
     if (!hs_in_sort) hipLaunchKernelGGL(k_hscalars, dim3(gN), dim3(256), 0, s2, p->d_a, p->d_t[0], p->d_t[1], p->d_t[2], N);
     K16_HIP(ctx, hipGetLastError());
@@ -1015,10 +1047,16 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     };
     G1Xyzz pi_a, pib1, pi_c, pih;
     G2Xyzz pi_b;
-    static const bool probe_no_witness = getenv("K16_PROBE_NO_WITNESS") != nullptr; // lab: WRONG proofs, chain + H alone
+    // (lab builds only, -DK16_LAB: K16_LAB_PROBE_NO_WITNESS runs the witness MSMs over ONE point -- WRONG proofs, what the
+    // chain + H MSM cost alone; libk16.so has neither the code nor the name)
+#ifdef K16_LAB
+    static const bool probe_no_witness = getenv("K16_LAB_PROBE_NO_WITNESS") != nullptr;
     const uint64_t    n_wit = probe_no_witness ? 1 : p->n_vars;
+#else
+    const uint64_t    n_wit = p->n_vars;
+#endif
     unsigned wc = 13;
-    if (const char* e = getenv("K16_WITNESS_C")) wc = (unsigned)atoi(e);
+    if (ctx->tune.witness_c) wc = (unsigned)ctx->tune.witness_c;
     if (p->n_vars < (1u << 17)) wc = 0; // small circuits: automatic
     // All five MSMs are enqueued back to back; their host tails (conversion + Horner, ~0.3 ms each, ~1.2 ms for
     // G2) run while later MSMs occupy the GPU.
@@ -1040,7 +1078,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
             int         lane, group, tab;
             const void* rows;
         } const order[4] = {{0, K16_G1, 0, p->d_A}, {2, K16_G2, 2, p->d_B2}, {1, K16_G1, 3, p->d_C}, {0, K16_G1, 1, p->d_B1}};
-        static const bool split = getenv("K16_NO_SPLIT_CLASSES") == nullptr;
+        const bool split = !ctx->tune.no_split_classes;
         for (int phase = split ? 1 : 0; phase <= (split ? 2 : 0); phase++)
             for (int k = 0; k < 4; k++) {
                 ctx->cur_lane = order[k].lane;
@@ -1055,7 +1093,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         const uint64_t* skip_ac = (const uint64_t*)p->d_skip_ac;
         const uint64_t* skip_b  = p->b_sort ? (const uint64_t*)p->d_skip_b : skip_ac;
         // K16_B2_FIRST=1 (lab): B2 leads on lane 2 and owns the SHARED sort, the G1 MSMs read it
-        static const bool b2_lead_env = getenv("K16_B2_FIRST") != nullptr;
+        const bool        b2_lead_env = ctx->tune.b2_first;
         const bool        b2_lead = b2_lead_env && !p->b_sort;
         const int         own     = b2_lead ? 2 : 0; // lane whose sort A and C read
         if (p->b_sort || b2_lead) {
@@ -1078,7 +1116,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
         ctx->skip_next       = skip_ac;
         if ((rc = k16_msm_enqueue_prepared(ctx, K16_G1, p->d_C, p->d_wtns, n_wit))) return rc;
         // B1 / B2 on a sort that contains their (0,0) rows: the accumulation steps over them (k_accumulate_skip)
-        static const bool acc_skip_on = getenv("K16_NO_ACC_SKIP") == nullptr;
+        const bool        acc_skip_on = !ctx->tune.no_acc_skip;
         const bool        b_skip = acc_skip_on && !p->b_sort && !p->b_derive && p->d_skip_ac;
         if (p->b_derive && !b2_lead) {
             // B2 first (lane 2): its lists come from lane 0's partition without B's (0,0) rows; B1 (lane 0, after A) reads them
@@ -1136,6 +1174,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     Fr      rs = to_mont(fmul(rr, ss)); // = r*s mod r in standard form (groth16.cpp:348-349)
     uint8_t rs_b[32];
     memcpy(rs_b, rs.v, 32);
+    WipeOnExit wipe_rr{&rr, sizeof rr}, wipe_ss{&ss, sizeof ss}, wipe_rs{&rs, sizeof rs}, wipe_rsb{rs_b, 32};
     G1Xyzz d1_rs_neg = pneg(h_mul(d1, rs_b));
 
     ht("H enqueued + host blinding");
@@ -1155,7 +1194,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     };
     // results come back in enqueue order: classes A, B2, C, B1, H; bucket path B2, A, C, B1, H with a sort of its own for B,
     // A, C, B2, B1, H with derived lists for B (K16_B_DERIVE), A, C, B1, B2, H without
-    const bool b2_first = !p->cls && (p->b_sort || getenv("K16_B2_FIRST") != nullptr);
+    const bool b2_first = !p->cls && (p->b_sort || ctx->tune.b2_first);
     if (b2_first && (rc = finish_b2())) return rc;
     if ((rc = k16_msm_finish_group(ctx, K16_G1, &pi_a, nullptr))) return rc;
     ht("A finished");

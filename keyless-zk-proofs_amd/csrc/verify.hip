@@ -582,7 +582,7 @@ extern "C" int k16_vk_create(k16_ctx* ctx, const void* alpha1, const void* beta2
     }
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return fail("k16_vk_create", e);
     // ---- the wave-cooperative path (latency: one wavefront per proof).  Any failure here only leaves it switched off.
-    if (!getenv("K16_VERIFY_NO_COOP")) {
+    if (!ctx->tune.verify_no_coop) {
         const CoopProgram* P = coop_program();
         Fp12               eab;
         if (P && hipMemcpy(&eab, vk->d_eab, sizeof eab, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -724,7 +724,7 @@ static int verify_coop(k16_ctx* ctx, const k16_vk* vk, const void* h_proofs, con
     D.n_slots = P->n_slots;
     D.target_const = P->target_const;
     for (int i = 0; i < 12; i++) D.out_slot[i] = P->out_slot[i];
-    static const bool trace = getenv("K16_VERIFY_COOP_TRACE") != nullptr;
+    const bool        trace = ctx->tune.verify_coop_trace;
     uint64_t*         d_dbg = nullptr;
     if (trace) K16_HIP(ctx, tmp.alloc((void**)&d_dbg, 16 * 8));
     // The latency case (n <= 64, no GT output): inputs and flags go through the context's pinned, device-mapped staging
@@ -802,7 +802,7 @@ extern "C" int k16_verify_batch(k16_ctx* ctx, const k16_vk* vk, const void* h_pr
     // wavefront per proof, ~1-2 ms whatever n is up to the number of CUs, instead of the ~45 ms one lane needs for a
     // pairing.  It records the generic case only: a proof with a zero point, or whose vk_x is the point at infinity, sends
     // the batch to the general path below (same flags: both compute the same GT value for every other proof).
-    static const uint64_t coop_max = getenv("K16_VERIFY_COOP_MAX") ? strtoull(getenv("K16_VERIFY_COOP_MAX"), nullptr, 10) : 2048;
+    const uint64_t coop_max = ctx->tune.verify_coop_max;
     if (vk->coop && n <= coop_max) {
         bool generic = true;
         for (uint64_t i = 0; i < n && generic; i++) {

@@ -19,7 +19,7 @@ FQ, FR = 0, 1
 FQ9, FR9, FQ2N = 2, 3, 4          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
 G1_ENG9, G2_ENG2N = 2, 3
 OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT, OP_LAZY_ADDMUL, OP_LAZY_SUBMUL = range(9)
-PT_ADD, PT_MADD, PT_DBL = range(3)
+PT_ADD, PT_MADD, PT_DBL, PT_MADD_ACC = range(4)
 AFF_BYTES = {G1: 64, G2: 128, G1_ENG9: 64, G2_ENG2N: 128}
 XYZZ_BYTES = {G1: 128, G2: 256, G1_ENG9: 128, G2_ENG2N: 256}
 
@@ -41,6 +41,10 @@ SYMBOLS = [
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
     "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_fullprover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
     "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_verify_coop_gt", "k16_pairing_vec",
+    "k16_msm_sharded_create", "k16_msm_sharded_destroy", "k16_msm_sharded_count", "k16_msm_sharded_range", "k16_msm_sharded_ctx",
+    "k16_msm_sharded_last_error", "k16_msm_sharded_set_bases", "k16_msm_sharded_set_bases_device", "k16_msm_sharded_run",
+    "k16_msm_sharded_run_device", "k16_msm_sharded_last_ms",
+    "k16_rank_comm_unique_id", "k16_rank_comm_load_error", "k16_rank_comm_create", "k16_rank_comm_destroy", "k16_rank_comm_allgather_fold",
 ]
 
 _lib = None
@@ -125,6 +129,27 @@ def load():
     L.k16_verify_batch.argtypes = [vp, vp, vp, vp, u64, vp]
     L.k16_verify_coop_gt.argtypes = [vp, vp, vp, vp, u64, vp]
     L.k16_pairing_vec.argtypes = [vp, vp, vp, u64, vp]
+    L.k16_msm_sharded_create.argtypes = [C.POINTER(i32), i32, i32, u64, C.POINTER(vp)]
+    L.k16_msm_sharded_destroy.argtypes = [vp]
+    L.k16_msm_sharded_destroy.restype = None
+    L.k16_msm_sharded_count.argtypes = [vp]
+    L.k16_msm_sharded_range.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(u64)]
+    L.k16_msm_sharded_ctx.argtypes = [vp, i32]
+    L.k16_msm_sharded_ctx.restype = vp
+    L.k16_msm_sharded_last_error.argtypes = [vp]
+    L.k16_msm_sharded_last_error.restype = C.c_char_p
+    L.k16_msm_sharded_set_bases.argtypes = [vp, vp]
+    L.k16_msm_sharded_set_bases_device.argtypes = [vp, i32, vp]
+    L.k16_msm_sharded_run.argtypes = [vp, vp, vp, vp]
+    L.k16_msm_sharded_run_device.argtypes = [vp, C.POINTER(vp), vp, vp]
+    L.k16_msm_sharded_last_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.k16_rank_comm_unique_id.argtypes = [vp]
+    L.k16_rank_comm_load_error.argtypes = []
+    L.k16_rank_comm_load_error.restype = C.c_char_p
+    L.k16_rank_comm_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.k16_rank_comm_destroy.argtypes = [vp]
+    L.k16_rank_comm_destroy.restype = None
+    L.k16_rank_comm_allgather_fold.argtypes = [vp, i32, vp, vp, vp]
     _lib = L
     return L
 
@@ -174,7 +199,8 @@ class Context:
 
     def close(self):
         if self.h:
-            self.L.k16_ctx_destroy(self.h)
+            if not getattr(self, "borrowed", False):   # a ShardedMsm's contexts belong to it
+                self.L.k16_ctx_destroy(self.h)
             self.h = None
 
     def _chk(self, rc):
@@ -481,3 +507,104 @@ def pairing_vec(ctx, g1, g2):
     out = np.zeros((n, 384), dtype=np.uint8)
     ctx._chk(ctx.L.k16_pairing_vec(ctx.h, _p(g1), _p(g2), n, _p(out)))
     return out
+
+
+class ShardedMsm:
+    """One MSM sharded over several devices from ONE process (include/k16.h: k16_msm_sharded_*): a context per entry of
+    `devices` (entries may repeat), contiguous shards, host-side EC-add fold of the per-shard partial results."""
+
+    def __init__(self, devices, group, n):
+        self.L = load()
+        self.group, self.n = group, n
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.L.k16_msm_sharded_create(arr, len(devices), group, n, C.byref(h))
+        if rc:
+            raise K16Error(rc, "k16_msm_sharded_create")
+        self.h = h
+
+    def _chk(self, rc):
+        if rc:
+            raise K16Error(rc, (self.L.k16_msm_sharded_last_error(self.h) or b"").decode())
+
+    def count(self):
+        return self.L.k16_msm_sharded_count(self.h)
+
+    def shard_range(self, r):
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.k16_msm_sharded_range(self.h, r, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def shard_ctx(self, r):
+        """A borrowed Context over shard r's k16_ctx (owned by the ShardedMsm: do not close it)."""
+        c = Context.__new__(Context)
+        c.L, c.h, c.borrowed = self.L, C.c_void_p(self.L.k16_msm_sharded_ctx(self.h, r)), True
+        c.device = -1
+        return c
+
+    def set_bases(self, h_bases):
+        h_bases = np.ascontiguousarray(h_bases)
+        assert h_bases.nbytes == self.n * AFF_BYTES[self.group]
+        self._chk(self.L.k16_msm_sharded_set_bases(self.h, _p(h_bases)))
+
+    def set_bases_device(self, r, d_slice):
+        self._chk(self.L.k16_msm_sharded_set_bases_device(self.h, r, d_slice.ptr if d_slice is not None else None))
+
+    def run(self, h_scalars):
+        h_scalars = np.ascontiguousarray(h_scalars)
+        assert h_scalars.nbytes == self.n * 32
+        x = np.zeros(XYZZ_BYTES[self.group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[self.group], dtype=np.uint8)
+        self._chk(self.L.k16_msm_sharded_run(self.h, _p(h_scalars), _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    def run_device(self, d_scalars):
+        arr = (C.c_void_p * len(d_scalars))(*[d.ptr for d in d_scalars])
+        x = np.zeros(XYZZ_BYTES[self.group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[self.group], dtype=np.uint8)
+        self._chk(self.L.k16_msm_sharded_run_device(self.h, arr, _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    def last_ms(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.L.k16_msm_sharded_last_ms(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(shards_ms=a.value, fold_ms=b.value, total_ms=c.value)
+
+    def close(self):
+        if self.h:
+            self.L.k16_msm_sharded_destroy(self.h)
+            self.h = None
+
+
+class RankComm:
+    """One process per GPU: the shards' partial results exchanged with ONE ncclAllGather (RCCL, dlopen'ed by the library) and
+    folded on every rank (include/k16.h: k16_rank_comm_*).  `unique_id` = the 128 bytes rank 0 got from RankComm.unique_id(),
+    handed to the other ranks by the launcher."""
+
+    @staticmethod
+    def unique_id():
+        L = load()
+        buf = np.zeros(128, dtype=np.uint8)
+        rc = L.k16_rank_comm_unique_id(_p(buf))
+        if rc:
+            raise K16Error(rc, (L.k16_rank_comm_load_error() or b"").decode())
+        return buf.tobytes()
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.ctx, self.L = ctx, ctx.L
+        h = C.c_void_p()
+        uid = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        ctx._chk(self.L.k16_rank_comm_create(ctx.h, rank, world, _p(uid), C.byref(h)))
+        self.h, self.world = h, world
+
+    def allgather_fold(self, group, partial_xyzz):
+        part = np.frombuffer(partial_xyzz, dtype=np.uint8).copy()
+        x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
+        self.ctx._chk(self.L.k16_rank_comm_allgather_fold(self.h, group, _p(part), _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    def close(self):
+        if self.h:
+            self.L.k16_rank_comm_destroy(self.h)
+            self.h = None

@@ -4,7 +4,14 @@ results, then an EC-add fold.  No bucket-level data ever crosses xGMI.
 
 RCCL has no elliptic-curve reduction op, so the exchange is an all_gather of raw XYZZ bytes
 (128 B for G1, 256 B for G2 per rank) followed by k16_points_sum on every rank.
-The same code runs over gloo on CPU tensors (tests/test_multi_process.py).
+
+Two carriers of the same exchange:
+  * `RankExchange` -- the library's own C entry points (include/k16.h: k16_rank_comm_*: ncclCommInitRank + ONE ncclAllGather
+    per MSM, RCCL dlopen'ed by libk16.so), what a C++ service with one prover process per GPU calls; this module is a ctypes
+    caller of it.  The 128-byte communicator id travels through the launcher's store (torch.distributed here).
+  * `exchange_start` / `exchange_finish` -- torch.distributed's all_gather_into_tensor, asynchronous, which bench.py's weak
+    mode overlaps with the next step's GPU work; the same code runs over gloo on CPU tensors (tests/test_multi_process.py).
+One process driving several devices needs neither: k16.ShardedMsm (k16_msm_sharded_*) folds on the host.
 """
 import numpy as np
 
@@ -75,3 +82,22 @@ def exchange_finish(handle):
 def exchange_and_fold(dist, group, partial_xyzz, device=None):
     """all_gather every rank's partial MSM result and fold them. Returns (xyzz_bytes, affine_bytes)."""
     return exchange_finish(exchange_start(dist, group, partial_xyzz, device))
+
+
+class RankExchange:
+    """The exchange through libk16.so's RCCL leg (k16_rank_comm_create / _allgather_fold).  `dist` is only the launcher's
+    store here: it carries rank 0's communicator id to the other ranks; the collective itself is the library's."""
+
+    def __init__(self, dist, ctx):
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [k16.RankComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        self.comm = k16.RankComm(ctx, rank, world, box[0])
+        self.world = world
+
+    def exchange_and_fold(self, group, partial_xyzz):
+        """all ranks' partial results gathered with ONE ncclAllGather and folded in rank order: (xyzz_bytes, affine_bytes)"""
+        return self.comm.allgather_fold(group, partial_xyzz)
+
+    def close(self):
+        self.comm.close()

@@ -6,6 +6,10 @@
 #include <cstdlib>
 #include <cstring>
 #include "bn254_curve.h"
+// intermediate values of acc9_madd (lazy limbs): the header calls this hook when it is defined
+namespace k16 { struct Fq9; }
+static void fq9_hook(const char* what, const k16::Fq9& v);
+#define K16_FQ9_HOOK(what, v) fq9_hook(what, v)
 #include "bn254_fq9.h"
 using namespace k16;
 
@@ -48,6 +52,15 @@ static bool normalised(const Fq9& v)
     return true;
 }
 static int fails = 0;
+static int hook_calls = 0;
+static void fq9_hook(const char* what, const k16::Fq9& v)
+{
+    // "ym": +-y lazy, limbs < 2^30 (no wrapped negative limb); "D": Q - X3 + 10p lazy, limbs < 3 * 2^29
+    const uint32_t lim = what[0] == 'y' ? (1u << 30) : 3u * (1u << 29);
+    hook_calls++;
+    for (int i = 0; i < 9; i++)
+        if (v.l[i] >= lim) { fails++; if (fails < 20) printf("FAIL lazy limb bound of %s: limb %d = %08x\n", what, i, v.l[i]); }
+}
 #define CHECK(c, msg) do { if (!(c)) { fails++; if (fails < 20) printf("FAIL %s (line %d)\n", msg, __LINE__); } } while (0)
 
 static bool pt_bounds_ok(const Xyzz9& p)
@@ -194,6 +207,105 @@ int main()
         G1Xyzz c3 = padd_mixed(padd_mixed(c, tab[(k + 1) % NP == 7 ? 8 : (k + 1) % NP]), pneg(tab[(k + 1) % NP == 7 ? 8 : (k + 1) % NP]));
         Xyzz9  n3 = xyzz9_from_canonical(c3);
         CHECK(same_point_repr(padd_mixed9(n3, tab9[k]), padd_mixed(c3, tab[k])), "madd P+P (zz != 1)");
+    }
+    // ---- the bucket accumulator (acc9_madd: W = +-Y with a flag, lazy subtractions): the same XYZZ representation as the
+    // reference's mixed addition for every step of random walks over signed rows, incl. (0,0) rows, P + P, P + (-P),
+    // infinity + P, and rows / accumulators at the edges of their bounds
+    {
+        auto acc_ok = [&](const Acc9& a) {
+            return normalised(a.x) && normalised(a.w) && normalised(a.zz) && normalised(a.zzz) && below_kp(a.x, 8) &&
+                   below_kp(a.w, 4) && below_kp(a.zz, 2) && below_kp(a.zzz, 2) && a.neg <= 1u;
+        };
+        // table rows with y in the top sliver [top limb of 2p, 2p): y + p has the same residue and is < 2p for y < p
+        Aff9 tabhi[NP];
+        for (int k = 0; k < NP; k++) {
+            tabhi[k] = tab9[k];
+            if (k == 7) continue;
+            Fq9 pp;
+            for (int i = 0; i < 9; i++) pp.l[i] = Fq9C::P[i];
+            Fq9 yc = fq9_from_fq(tab[k].y); // < 2p
+            Fq9 y1 = fadd9(yc, pp);
+            if (below_kp(yc, 1) && below_kp(y1, 2)) tabhi[k].y = y1;
+        }
+        for (int walk = 0; walk < 400; walk++) {
+            G1Xyzz c = G1Xyzz::zero();
+            Acc9   a = Acc9::zero();
+            a.neg    = walk & 1u;
+            for (int step = 0; step < 80; step++) {
+                int      k    = (int)(rnd() % NP);
+                uint32_t sign = (uint32_t)(rnd() & 1u);
+                const Aff9* t9 = (walk % 3 == 2) ? tabhi : tab9;
+                int mode = (int)(rnd() % 16);
+                if (step == 1 && walk % 4 == 0) mode = 12; // P + P right after infinity + P
+                if (mode == 12 && !c.is_zero()) {
+                    // add the accumulator's own affine value: doubling through the mixed addition (zz != 1 in general)
+                    G1Aff self = to_affine(c);
+                    Aff9  s9   = aff9_from_canonical(self);
+                    G1Aff arg  = sign ? pneg(self) : self; // row such that (sign ? -row : row) == self
+                    Aff9  a9   = sign ? aff9_from_canonical(arg) : s9;
+                    c = padd_mixed(c, self);
+                    acc9_madd(a, a9, sign);
+                } else if (mode == 13 && !c.is_zero()) {
+                    // add minus the accumulator: infinity through the general formulas
+                    G1Aff self = to_affine(c);
+                    G1Aff ng   = pneg(self);
+                    Aff9  a9   = sign ? aff9_from_canonical(self) : aff9_from_canonical(ng);
+                    c = padd_mixed(c, ng);
+                    acc9_madd(a, a9, sign);
+                    CHECK(a.is_zero() && c.is_zero(), "acc9: P + (-P)");
+                } else {
+                    G1Aff arg = sign ? pneg(tab[k]) : tab[k];
+                    c = padd_mixed(c, arg);
+                    acc9_madd(a, t9[k], sign);
+                }
+                CHECK(acc_ok(a), "acc9 bounds");
+                Xyzz9 x = a.to_xyzz();
+                CHECK(normalised(x.y) && (below_kp(x.y, 4) || fq9_to_fq(x.y) == Fq::zero()), "acc9 -> xyzz Y bound");
+                CHECK(same_point_repr(x, c), "acc9: XYZZ representation equal to the reference's mixed addition");
+            }
+        }
+        // from an XYZZ point at its bounds (what the aff + aff first addition hands over): X up to 8p, Y up to 4p
+        for (int it = 0; it < 2000; it++) {
+            int    k = (int)(rnd() % NP), k2 = (int)(rnd() % NP);
+            if (k == 7 || k2 == 7) continue;
+            G1Xyzz c = padd_mixed(padd_mixed(G1Xyzz::zero(), tab[k]), tab[(k + 5) % NP == 7 ? 9 : (k + 5) % NP]);
+            Xyzz9  n = xyzz9_from_canonical(c);
+            Fq9 pp;
+            for (int i = 0; i < 9; i++) pp.l[i] = Fq9C::P[i];
+            for (int j = 0; j < (it % 6); j++) n.x = fadd9(n.x, pp);  // < 2p + 5p
+            for (int j = 0; j < (it % 2); j++) n.y = fadd9(n.y, pp);  // < 3p
+            Acc9 a = Acc9::from_xyzz(n);
+            uint32_t sign = it & 1u;
+            acc9_madd(a, tab9[k2], sign);
+            G1Xyzz w = padd_mixed(c, sign ? pneg(tab[k2]) : tab[k2]);
+            CHECK(same_point_repr(a.to_xyzz(), w), "acc9 from an XYZZ point at its bounds");
+        }
+        // the lazy forms on their own, at the edges: y with the top limb of 2p (3p - y must not lend from a negative top
+        // limb), all-ones / all-zero low limbs; X3 just below 8p
+        for (int it = 0; it < 4000; it++) {
+            Fq  zc = rand_fq();
+            Fq9 Z  = fq9_from_fq(zc), y;
+            for (int i = 0; i < 8; i++) y.l[i] = (it & 1) ? Fq9C::MASK : ((it & 2) ? 0u : (uint32_t)rnd() & Fq9C::MASK);
+            y.l[8] = (it % 5 == 0) ? Fq9C::KP2[8] : (uint32_t)(rnd() % (Fq9C::KP2[8] + 1u));
+            if (!below_kp(y, 2)) { for (int i = 0; i < 8; i++) y.l[i] = 0; } // top limb of 2p with low limbs below 2p's
+            Fq9 ym;
+            for (int i = 0; i < 9; i++) ym.l[i] = fq9_lent_kp<3>(i) - y.l[i];
+            fq9_hook("ym", ym);
+            CHECK(fq9_to_fq(fmul9(ym, Z)) == fmul(fneg(fq9_to_fq(y)), zc), "lazy 3p - y times z");
+            Fq9 x3 = y; // reuse the pattern for X3 < 8p: scale the top limb
+            x3.l[8] = (it % 5 == 0) ? Fq9C::KP8[8] : (uint32_t)(rnd() % (Fq9C::KP8[8] + 1u));
+            if (!below_kp(x3, 8)) { for (int i = 0; i < 8; i++) x3.l[i] = 0; }
+            Fq9 q = fmul9(Z, Z), D;
+            for (int i = 0; i < 9; i++) D.l[i] = q.l[i] + fq9_lent_kp<10>(i) - x3.l[i];
+            fq9_hook("D", D);
+            CHECK(fq9_to_fq(fmul9(D, Z)) == fmul(fsub(fq9_to_fq(q), fq9_to_fq(x3)), zc), "lazy q - x3 + 10p times z");
+            // X3 = rr + 6p - ppp - 2q at ppp + 2q close to 6p and at 0
+            Fq9 rr = fmul9(Z, y), ppp = (it & 4) ? fq9_zero() : y /* < 2p */, qq = (it & 8) ? fq9_zero() : y;
+            Fq9 r3 = fq9_x3(rr, ppp, qq);
+            CHECK(normalised(r3) && below_kp(r3, 8), "fq9_x3 bound");
+            CHECK(fq9_to_fq(r3) == fsub(fsub(fq9_to_fq(rr), fq9_to_fq(ppp)), fdbl(fq9_to_fq(qq))), "fq9_x3 value");
+        }
+        CHECK(hook_calls > 10000, "acc9 hook saw the lazy values");
     }
     // ---- Fr on the same representation (NTT chain): values, the < 2r invariant, conversions
     {

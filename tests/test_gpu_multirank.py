@@ -56,3 +56,32 @@ def test_bench_one_rank_per_gpu_over_rccl():
         pytest.skip("needs >= 2 GPUs; this box has %d" % n)
     d = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--log2n", "18", "--proofs", "0", "--no-cpu-baseline"], {})
     assert d["ranks_seen"] == 2 and d["result_checked"] is True and "RCCL" in d["config"]["sharding"]
+
+
+def test_bench_strong_mode_exchanges_through_the_c_entry_points():
+    """BASELINE config 5's shape on one rank with the distributed path forced: the exchange is libk16.so's own RCCL leg
+    (k16_rank_comm_create / k16_rank_comm_allgather_fold -- ncclCommInitRank + ncclAllGather issued by the library), world
+    size 1 on the one-GPU boxes; the folded result is checked against the closed form."""
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--mode", "strong", "--total-log2n", "20", "--proofs", "0",
+                "--no-cpu-baseline"], {"K16_BENCH_FORCE_DIST": "1", "K16_BENCH_PREWARM": "2"})
+    assert d["result_checked"] is True and d["scaling"] == "strong"
+    assert "k16_rank_comm" in d["config"]["sharding"], d["config"]
+
+
+def test_bench_strong_mode_two_ranks_over_the_c_exchange():
+    """Two GPUs: one rank per GPU, the 2^22-point MSM sharded, exchange through k16_rank_comm_* (skipped on one-GPU boxes)."""
+    import k16
+    n = k16.load().k16_device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs; this box has %d" % n)
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "strong", "--total-log2n", "22", "--proofs", "0",
+                "--no-cpu-baseline"], {"K16_BENCH_PREWARM": "2"})
+    assert d["ranks_seen"] == 2 and d["result_checked"] is True and "k16_rank_comm" in d["config"]["sharding"]
+
+
+def test_bench_one_process_sharded_msm():
+    """k16_msm_sharded_* under bench.py: ONE process, the strong-mode MSM cut into shards over the visible devices (two
+    contexts on device 0 on a one-GPU box), scalars handed over in host memory, host-side fold, closed form checked."""
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--mode", "strong", "--total-log2n", "22", "--proofs", "0",
+                "--no-cpu-baseline"], {"K16_BENCH_SHARDS": "2", "K16_BENCH_PREWARM": "1"})
+    assert d["result_checked"] is True and "k16_msm_sharded" in d["config"]["sharding"]

@@ -332,15 +332,33 @@ def test_msm_repeatability_stress(ctx):
     d_s.free()
 
 
-def test_generic_atomic_sort_path_agrees(ctx, monkeypatch):
+def test_generic_atomic_sort_path_agrees(monkeypatch):
     """n > 2^24 uses the generic global-atomic bucket sort instead of the LDS partition sort; force it on a small
-    input and compare with the oracle (K16_ATOMIC_SORT is read at every call)."""
+    input and compare with the oracle (K16_ATOMIC_SORT is read when a context is created)."""
+    import k16
     n = 5000
     bases = ol.gen_points(0, 3, n)
     monkeypatch.setenv("K16_ATOMIC_SORT", "1")
-    for kind in ("full256", "witness"):
-        _check_msm(ctx, 0, bases, np_scalars(77, n, kind))
-    _check_msm(ctx, 1, ol.gen_points(1, 3, 600), np_scalars(78, 600, "full256"))
+    c2 = k16.Context(0)
+    try:
+        for kind in ("full256", "witness"):
+            _check_msm(c2, 0, bases, np_scalars(77, n, kind))
+        _check_msm(c2, 1, ol.gen_points(1, 3, 600), np_scalars(78, 600, "full256"))
+        # a zero-row mask on this sort is dropped, not refused (ADVICE r4): same sum
+        d_b = c2.to_device(bases)
+        prep = c2.bases_prepare(k16.G1, d_b, n)
+        mask = c2.alloc(((n + 63) // 64) * 8)
+        c2._chk(c2.L.k16_msm_zero_row_mask(c2.h, k16.G1, prep.ptr, n, mask.ptr))
+        sc = np_scalars(79, n, "witness")
+        d_s = c2.to_device(sc)
+        c2._chk(c2.L.k16_msm_set_zero_row_mask(c2.h, mask.ptr))
+        c2.msm_enqueue_prepared(k16.G1, prep, d_s, n)
+        _, got = c2.msm_finish(k16.G1)
+        assert got == ol.msm(0, bases, sc, nthreads=4)[1]
+        for d in (d_b, prep, mask, d_s):
+            d.free()
+    finally:
+        c2.close()
 
 
 def test_msm_pipelined_enqueue_finish_fifo(ctx):
@@ -635,6 +653,28 @@ def test_point_ops_hot_path_formulas(ctx, sel, group):
                     # P + (-P): zz3 = 0 by the general formula; x3, y3 are whatever it leaves (equal mod p)
                     assert ol.pt_eq(group, bytes(got[i]), want[i]) and bytes(got[i][xb // 2:]) == bytes(xb // 2), (sel, op, i)
                 assert bytes(got[i]) == want[i], (sel, op, ka, kb, i)
+    if group == 0:
+        # the bucket accumulation's own addition (acc9_madd, round 5): W = +-Y with a flag, the entry's sign inside the
+        # addition, lazy subtractions -- every branch again, both signs, both flag values, accumulator at X < 8p, Y < 4p
+        def neg_aff(row):
+            y = int.from_bytes(bytes(row[32:]), "little")
+            out = row.copy()
+            if y:
+                out[32:] = np.frombuffer((pm.Q - y).to_bytes(32, "little"), dtype=np.uint8)
+            return out
+        p2n = np.stack([neg_aff(r) for r in p2a])
+        for sign in (0, 1):
+            # result = p1 + (sign ? -row : row); rows 2 / 3 must stay P + P / P + (-P): hand the kernel the row whose signed
+            # value is the affine point of the table above
+            rows = p2n if sign else p2a
+            want = [ol.pt_op(group, ol.PT_MADD, bytes(p1[i]), bytes(p2a[i])) for i in range(n)]
+            for flag in (0, 1):
+                for ka in (0, 1, 2):
+                    got = ctx.point_op_vec(selv, k16.op_bound(k16.PT_MADD_ACC, ka, sign | (flag << 1)), p1, rows)
+                    for i in range(n):
+                        if i == 3:
+                            assert ol.pt_eq(group, bytes(got[i]), want[i]) and bytes(got[i][xb // 2:]) == bytes(xb // 2), (sign, flag, ka)
+                        assert bytes(got[i]) == want[i], ("acc9_madd", sign, flag, ka, i)
 
 
 # ---------------------------------------------------------------- full-size parity (BASELINE config 3 at scale 1.0)
@@ -734,7 +774,7 @@ def test_msm_g2_2p20_vs_oracle(ctx, kind):
         ctx.set_window_bits(0)
 
 
-def test_msm_more_giant_buckets_than_the_giant_list_holds(ctx, monkeypatch):
+def test_msm_more_giant_buckets_than_the_giant_list_holds(monkeypatch):
     """300 buckets with > 2048 segments each (K16_SEG=1: one entry per segment): the giant list holds 256, the rest must
     be folded through the medium path (k_classify) -- before the fix they kept only their first partial."""
     vals, copies = 300, 2100
@@ -745,7 +785,12 @@ def test_msm_more_giant_buckets_than_the_giant_list_holds(ctx, monkeypatch):
     scalars[:, :2] = v.view(np.uint8).reshape(n, 2)
     _, want = ol.msm(0, bases, scalars, nthreads=os.cpu_count() or 8)
     monkeypatch.setenv("K16_SEG", "1")
-    _, got = ctx.msm(0, bases, scalars)
+    import k16
+    c2 = k16.Context(0)          # the switch is read when a context is created
+    try:
+        _, got = c2.msm(0, bases, scalars)
+    finally:
+        c2.close()
     assert got == want
 
 

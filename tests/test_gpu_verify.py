@@ -246,11 +246,15 @@ def test_wave_cooperative_verifier_gt_values_and_flags(ctx, toy_paths, monkeypat
     V.close()
     # the general path alone (cooperative path switched off at key creation) gives the same flags
     monkeypatch.setenv("K16_VERIFY_NO_COOP", "1")
-    V2 = k16.VerifyingKey(ctx, vk)
-    assert V2.verify_batch([c[0] for c in cases], [[c[1]] for c in cases]) == want
-    with pytest.raises(k16.K16Error):
-        V2.coop_gt([known], [[2]])
-    V2.close()
+    ctx2 = k16.Context(0)            # the switch is read when a context is created
+    try:
+        V2 = k16.VerifyingKey(ctx2, vk)
+        assert V2.verify_batch([c[0] for c in cases], [[c[1]] for c in cases]) == want
+        with pytest.raises(k16.K16Error):
+            V2.coop_gt([known], [[2]])
+        V2.close()
+    finally:
+        ctx2.close()
 
 
 def test_wave_cooperative_verifier_several_public_inputs(ctx):
@@ -299,9 +303,13 @@ def test_verifier_rejects_non_canonical_and_off_curve_points(ctx, toy_paths, mon
            bump(known, 0, 2 * pm.Q),           # A.x + p, A.y + p, B.x.a + p, B.y.b + p, C.x + p, A.x + 2p: same residues
            bump(known, 32, 1), bump(known, 96, 1), bump(known, 224, 1)]   # off the curve / the twist
     for no_coop in (False, True):
+        cx = ctx
         if no_coop:
             monkeypatch.setenv("K16_VERIFY_NO_COOP", "1")
-        V = k16.VerifyingKey(ctx, vk)
+            cx = k16.Context(0)      # the switch is read when a context is created
+        V = k16.VerifyingKey(cx, vk)
         assert V.verify_batch([known] + bad, [[2]] * (1 + len(bad))) == [True] + [False] * len(bad), no_coop
         assert V.verify_batch([bad[0]], [[2]]) == [False]
         V.close()
+        if no_coop:
+            cx.close()

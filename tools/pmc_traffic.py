@@ -1,7 +1,7 @@
 """Reduces rocprofv3 --pmc counter CSVs (one counter per pass, as MI355X_MICROARCH.md prescribes) to the per-launch HBM-side
 traffic of the MSM's dominant kernel and writes profiles/pmc_traffic.json, which bench.py quotes as `roofline.traffic`.
 
-    python tools/pmc_traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> [out.json]
+    python tools/pmc_traffic.py <dir with FETCH_SIZE pass> <dir with WRITE_SIZE pass> [out.json] [commit]
 """
 import csv
 import glob
@@ -26,6 +26,19 @@ def main():
     fd, wd = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                             "profiles", "pmc_traffic.json")
+    # stamp: the commit the counters were taken at (argv[4], the GPU box has no .git) and a digest of the kernel's sources,
+    # which bench.py recomputes -- a tree with other kernel sources reports `traffic: null` instead of replaying this file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    digest = bench.kernel_sources_sha16()
+    commit = sys.argv[4] if len(sys.argv) > 4 else None
+    if commit is None:
+        try:
+            import subprocess
+            commit = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except Exception:
+            commit = None
     fetch, write = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
     acc = [k for k in fetch if "k_accumulate" in k and "Eng9" in k]
     if not acc:
@@ -37,6 +50,8 @@ def main():
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass), "
                   "K16_BENCH_DEPTH=1 bench.py --steps 3 --warmup 1 --proofs 0; per-kernel averages in profiles/r04/pmc_*_per_kernel.txt (tools/pmc_kernel.py on the same passes)",
         "kernel": k[:60],
+        "commit": commit,
+        "kernel_sources_sha16": digest,
         "launches_averaged": n,
         "FETCH_SIZE_KB_raw": f_kb,
         "WRITE_SIZE_KB": w_kb,
