@@ -49,6 +49,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MODMUL_PER_PAIR = 10            # SURVEY 8(d) secondary figure: one mixed add (8M + 2S) per (point, window) pair
 MODMUL_PEAK_G = 174.3           # measured on MI355X: radix-2^29 Montgomery multiply (fmul29 chains of tools/ubench.hip, 8 blocks
                                 # per CU), all CUs: profiles/r02/ubench_instruction_rates.log
+# The same ceiling from the HARDWARE's rate instead of this repository's own multiplication loop: v_mad_u64_u32 issues at
+# 31.9 T lane-operations/s chip-wide (profiles/r05/ubench2_instruction_costs.log, 8 waves per SIMD) and a 254-bit Montgomery
+# product on 29-bit limbs needs at least 162 of them (81 product + 81 reduction terms) -- every other instruction of fmul29
+# (masks, shifts, the nine m_k) counts against this figure.
+MAD_U64_LANE_OPS_T = 31.9
+MODMUL_PEAK_HW_G = MAD_U64_LANE_OPS_T * 1e3 / 162.0     # 196.9 G modmul/s
 KEYLESS = dict(n_vars=1343588, n_public=1, domain=1 << 21, n_coefs=8300000)   # circuit/README.md:77-83, SURVEY 8(d)
 
 
@@ -419,6 +425,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         hbm_bytes = (n_vars * (64 + 64 + 128 + 64) + N * 64) + n_vars * 32 + N * 32 + 6 * 2 * 32 * N + 44 * n_coefs + 5 * 3 * 32 * N
         roof = {"modmul_per_proof": mm_total, "modmul_breakdown": mm,
                 "alu_frac": mm_total / (p50 * 1e-3) / 1e9 / MODMUL_PEAK_G, "alu_peak_g_modmul_s": MODMUL_PEAK_G,
+                "alu_frac_hw": mm_total / (p50 * 1e-3) / 1e9 / MODMUL_PEAK_HW_G, "alu_peak_hw_g_modmul_s": MODMUL_PEAK_HW_G,
                 "hbm_bytes_per_proof": hbm_bytes, "hbm_frac": hbm_bytes / (p50 * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "basis": "algorithmic work of one proof (SURVEY 8(d)) over the p50 latency of one proof at a time; the path is "
                          "integer-multiply-issue bound (alu_frac is the figure to move), hbm_frac is reported because "
@@ -1021,6 +1028,10 @@ def main():
                     "peak": MODMUL_PEAK_G,
                     "frac": pts_per_launch * 16 * MODMUL_PER_PAIR / (iso * 1e-3) / 1e9 / MODMUL_PEAK_G if iso > 0 else None,
                     "frac_step": pts_per_launch * 16 * MODMUL_PER_PAIR / (elapsed / args.steps) / 1e9 / MODMUL_PEAK_G / (world if not strong else 1),
+                    # ... and against the hardware's multiply-add issue rate (31.9 T v_mad_u64_u32 lane-ops/s / 162 per product)
+                    "peak_hw": MODMUL_PEAK_HW_G,
+                    "frac_hw": pts_per_launch * 16 * MODMUL_PER_PAIR / (iso * 1e-3) / 1e9 / MODMUL_PEAK_HW_G if iso > 0 else None,
+                    "frac_step_hw": pts_per_launch * 16 * MODMUL_PER_PAIR / (elapsed / args.steps) / 1e9 / MODMUL_PEAK_HW_G / (world if not strong else 1),
                     "frac_step_basis": "the same algorithmic multiplications over the whole STEP (ms_per_step: sort, accumulation, "
                                        "fold, weighted sum, host combine of one MSM per lane, four lanes pipelined), per GPU",
                     "basis": "algorithmic 10 modmul x n x 16 windows per launch / kernel_ms_isolated; peak = measured "
