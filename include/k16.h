@@ -54,8 +54,10 @@ enum { K16_FQ = 0, K16_FR = 1 };
  * a | b) and the Eng9 / Eng2n point formulas of the MSM kernels.  Values are converted at the edges, exactly.
  * For these selectors bits 8-11 / 12-15 of `op` add that many multiples of the modulus to operand a / b after the
  * conversion (operands at the documented bounds: X < 8p, Y < 4p, ZZ < 2p ...); the result must not change. */
-enum { K16_FQ9 = 2, K16_FR9 = 3, K16_FQ2N = 4 };
-enum { K16_G1_ENG9 = 2, K16_G2_ENG2N = 3 };
+enum { K16_FQ9 = 2, K16_FR9 = 3, K16_FQ2N = 4,
+       K16_FQ2H = 5 /* Fq2 on a LANE PAIR (bn254_fq2pair.h: real part on the even lane, imaginary part on the odd one) -- what
+                       the G2 accumulation, fold and weighted-sum kernels execute since round 5; elements as for K16_FQ2N */ };
+enum { K16_G1_ENG9 = 2, K16_G2_ENG2N = 3, K16_G2_PAIR = 4 /* the XYZZ formulas instantiated on K16_FQ2H */ };
 #define K16_OP_BOUND_A(k) ((k) << 8)
 #define K16_OP_BOUND_B(k) ((k) << 12)
 enum { K16_OP_ADD = 0, K16_OP_SUB, K16_OP_NEG, K16_OP_MUL, K16_OP_SQR, K16_OP_TOMONT, K16_OP_FROMMONT,

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <algorithm>
 #include "ctx.h"
+#include "bn254_fq2pair.h"
 #include "bn254_fq9.h"
 
 using namespace k16;
@@ -521,6 +522,51 @@ __global__ void k_field_op_fq2n(int op, const Fq2* __restrict__ a, const Fq2* __
     }
     r[i] = fq2n_to_canonical(z);
 }
+// the same on LANE PAIRS (bn254_fq2pair.h): element i is worked on by lanes 2i (real part) and 2i + 1 (imaginary part)
+__global__ void __launch_bounds__(256) k_field_op_fq2h(int op, const Fq2* __restrict__ a, const Fq2* __restrict__ b, Fq2* __restrict__ r,
+                                                       uint64_t n)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const unsigned h = threadIdx.x & 1u;
+    if (i >= n) return; // both lanes of a pair leave together
+    const Fq2  xa = a[i], ya = b ? b[i] : Fq2::zero();
+    const Fq2h x{fq9_from_fq(h ? xa.b : xa.a)}, y{fq9_from_fq(h ? ya.b : ya.a)};
+    Fq2h       z;
+    switch (op) {
+    case K16_OP_ADD: z = fadd(x, y); break;
+    case K16_OP_SUB: z = fsub(x, y); break;
+    case K16_OP_NEG: z = fneg(x); break;
+    case K16_OP_MUL: z = fmul(x, y); break;
+    case K16_OP_SQR: z = fsqr(x); break;
+    default: z = Fq2h::zero();
+    }
+    Fq* out = reinterpret_cast<Fq*>(&r[i]) + h;
+    *out    = fq9_to_fq(z.v);
+}
+__global__ void __launch_bounds__(64) k_point_op_pair(int op, const G2Xyzz* __restrict__ p1, const void* __restrict__ p2,
+                                                      G2Xyzz* __restrict__ r, uint64_t n)
+{
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    const unsigned h = threadIdx.x & 1u;
+    if (i >= n) return;
+    auto half = [&](const Fq2& v) { return Fq2h{fq9_from_fq(h ? v.b : v.a)}; };
+    auto in2  = [&](const G2Xyzz& p) { return Xyzz<Fq2h>{half(p.x), half(p.y), half(p.zz), half(p.zzz)}; };
+    Xyzz<Fq2h> a = in2(p1[i]), z;
+    switch (op) {
+    case K16_PT_ADD: z = padd(a, in2(((const G2Xyzz*)p2)[i])); break;
+    case K16_PT_MADD: {
+        const G2Aff q = ((const G2Aff*)p2)[i];
+        z             = padd_mixed(a, Aff<Fq2h>{half(q.x), half(q.y)});
+    } break;
+    case K16_PT_DBL: z = pdbl(a); break;
+    default: z = Xyzz<Fq2h>::zero();
+    }
+    Fq* out = reinterpret_cast<Fq*>(&r[i]) + h; // x.a x.b y.a y.b zz.a zz.b zzz.a zzz.b
+    out[0]  = fq9_to_fq(z.x.v);
+    out[2]  = fq9_to_fq(z.y.v);
+    out[4]  = fq9_to_fq(z.zz.v);
+    out[6]  = fq9_to_fq(z.zzz.v);
+}
 // p1 gets X += 3*ka*p, Y += ka*p (ka <= 2: X < 8p, Y < 4p, the documented bounds of a stored Xyzz9); p2 likewise with
 // kb when it is an XYZZ point (an affine row must stay < 2p)
 __global__ void k_point_op_eng9(int op, unsigned ka, unsigned kb, const G1Xyzz* __restrict__ p1, const void* __restrict__ p2,
@@ -674,18 +720,18 @@ extern "C" int k16_synth_points(k16_ctx* c, int group, uint64_t start, uint64_t 
 extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, const void* h_b, void* h_r, uint64_t n)
 {
     return k16_guard(c, [&]() -> int {
-    if (!c || !h_a || !h_r || field < K16_FQ || field > K16_FQ2N) return K16_ERR_ARG;
+    if (!c || !h_a || !h_r || field < K16_FQ || field > K16_FQ2H) return K16_ERR_ARG;
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
     const bool lazy = op == K16_OP_LAZY_ADDMUL || op == K16_OP_LAZY_SUBMUL;
     if (lazy && ((field != K16_FQ9 && field != K16_FR9) || kb || ka > 14 || !h_b)) return K16_ERR_ARG;
-    if (!lazy && (ka || kb) && (field < K16_FQ9 || field == K16_FQ2N || ka > 6 || kb > 6)) return K16_ERR_ARG;
+    if (!lazy && (ka || kb) && (field < K16_FQ9 || field >= K16_FQ2N || ka > 6 || kb > 6)) return K16_ERR_ARG;
     if (!lazy && op > K16_OP_FROMMONT) return K16_ERR_ARG;
-    if (field == K16_FQ2N && op > K16_OP_SQR) return K16_ERR_ARG;
+    if (field >= K16_FQ2N && op > K16_OP_SQR) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(c, hipSetDevice(c->device));
     void * da = nullptr, *db = nullptr, *dr = nullptr;
-    size_t bytes = (size_t)n * (field == K16_FQ2N ? 64 : 32);
+    size_t bytes = (size_t)n * (field >= K16_FQ2N ? 64 : 32);
     K16_HIP(c, hipMalloc(&da, bytes));
     K16_HIP(c, hipMalloc(&dr, bytes));
     K16_HIP(c, hipMemcpyAsync(da, h_a, bytes, hipMemcpyHostToDevice, c->stream));
@@ -706,9 +752,12 @@ extern "C" int k16_field_op_vec(k16_ctx* c, int field, int op, const void* h_a, 
     else if (field == K16_FR9)
         hipLaunchKernelGGL((k_field_op9<Fr9C, FrParams>), dim3(grid), dim3(256), 0, c->stream, op, ka, kb, (const Fr*)da,
                            (const Fr*)db, (Fr*)dr, n);
-    else
+    else if (field == K16_FQ2N)
         hipLaunchKernelGGL(k_field_op_fq2n, dim3(grid), dim3(256), 0, c->stream, op, (const Fq2*)da, (const Fq2*)db,
                            (Fq2*)dr, n);
+    else
+        hipLaunchKernelGGL(k_field_op_fq2h, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, op, (const Fq2*)da,
+                           (const Fq2*)db, (Fq2*)dr, n);
     K16_HIP(c, hipGetLastError());
     K16_HIP(c, hipMemcpyAsync(h_r, dr, bytes, hipMemcpyDeviceToHost, c->stream));
     K16_HIP(c, hipStreamSynchronize(c->stream));
@@ -723,7 +772,7 @@ extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1,
                                 uint64_t n)
 {
     return k16_guard(c, [&]() -> int {
-    if (!c || !h_p1 || !h_r || group < K16_G1 || group > K16_G2_ENG2N) return K16_ERR_ARG;
+    if (!c || !h_p1 || !h_r || group < K16_G1 || group > K16_G2_PAIR) return K16_ERR_ARG;
     const unsigned ka = (op >> 8) & 15u, kb = (op >> 12) & 15u;
     op &= 0xff;
     if (op == K16_PT_MADD_ACC) {
@@ -731,6 +780,7 @@ extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1,
     } else if ((ka || kb) && (group != K16_G1_ENG9 || ka > 2 || kb > 2 || (kb && op != K16_PT_ADD)))
         return K16_ERR_ARG;
     if (op < K16_PT_ADD || op > K16_PT_MADD_ACC) return K16_ERR_ARG;
+    if (group == K16_G2_PAIR && op == K16_PT_MADD_ACC) return K16_ERR_ARG;
     if (n == 0) return K16_OK;
     K16_HIP(c, hipSetDevice(c->device));
     const bool g1 = group == K16_G1 || group == K16_G1_ENG9;
@@ -755,8 +805,11 @@ extern "C" int k16_point_op_vec(k16_ctx* c, int group, int op, const void* h_p1,
     else if (group == K16_G1_ENG9)
         hipLaunchKernelGGL(k_point_op_eng9, dim3(grid), dim3(64), 0, c->stream, op, ka, kb, (const G1Xyzz*)d1, d2,
                            (G1Xyzz*)dr, n);
-    else
+    else if (group == K16_G2_ENG2N)
         hipLaunchKernelGGL(k_point_op_eng2n, dim3(grid), dim3(64), 0, c->stream, op, (const G2Xyzz*)d1, d2,
+                           (G2Xyzz*)dr, n);
+    else
+        hipLaunchKernelGGL(k_point_op_pair, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, c->stream, op, (const G2Xyzz*)d1, d2,
                            (G2Xyzz*)dr, n);
     K16_HIP(c, hipGetLastError());
     K16_HIP(c, hipMemcpyAsync(h_r, dr, n * xb, hipMemcpyDeviceToHost, c->stream));

@@ -16,12 +16,12 @@ OPT_PIPELINED_MSM = 1
 OPT_GRAPHS = 2
 OPT_SHARED_GPU = 3
 FQ, FR = 0, 1
-FQ9, FR9, FQ2N = 2, 3, 4          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
-G1_ENG9, G2_ENG2N = 2, 3
+FQ9, FR9, FQ2N, FQ2H = 2, 3, 4, 5          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
+G1_ENG9, G2_ENG2N, G2_PAIR = 2, 3, 4
 OP_ADD, OP_SUB, OP_NEG, OP_MUL, OP_SQR, OP_TOMONT, OP_FROMMONT, OP_LAZY_ADDMUL, OP_LAZY_SUBMUL = range(9)
 PT_ADD, PT_MADD, PT_DBL, PT_MADD_ACC = range(4)
-AFF_BYTES = {G1: 64, G2: 128, G1_ENG9: 64, G2_ENG2N: 128}
-XYZZ_BYTES = {G1: 128, G2: 256, G1_ENG9: 128, G2_ENG2N: 256}
+AFF_BYTES = {G1: 64, G2: 128, G1_ENG9: 64, G2_ENG2N: 128, G2_PAIR: 128}
+XYZZ_BYTES = {G1: 128, G2: 256, G1_ENG9: 128, G2_ENG2N: 256, G2_PAIR: 256}
 
 
 def op_bound(op, ka=0, kb=0):

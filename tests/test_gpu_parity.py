@@ -591,7 +591,8 @@ def test_field_ops_hot_path_representation(ctx, field, sel):
             assert np.array_equal(got, want), (sel, op, ka, kb)
 
 
-def test_fq2_ops_hot_path_representation(ctx):
+@pytest.mark.parametrize("sel", ["FQ2N", "FQ2H"])
+def test_fq2_ops_hot_path_representation(ctx, sel):
     """Fq2n (Fq2 over the radix-2^29 field: fmul9_sum2 products, fred9 partial reductions) against the oracle's Fq2
     (f2field.cpp:94-176), including the reference's own KAT (2,2)*(3,3) = (0,12) (alt_bn128_test.cpp:12-30)."""
     import k16
@@ -604,16 +605,17 @@ def test_fq2_ops_hot_path_representation(ctx):
     b[0] = np.concatenate([mont(3), mont(3)])
     a[1], b[1] = 0, b[5]                   # 0 * y, and x - x, x + (-x) below
     b[2] = a[2]
+    selv = getattr(k16, sel)     # FQ2H: the same values with the two components on a lane pair (bn254_fq2pair.h, round 5)
     for op in (k16.OP_ADD, k16.OP_SUB, k16.OP_NEG, k16.OP_MUL, k16.OP_SQR):
-        got = ctx.field_op_vec(k16.FQ2N, op, a, b)
+        got = ctx.field_op_vec(selv, op, a, b)
         for i in range(n):
             want = ol.fq2_op(op, a[i].tobytes(), b[i].tobytes())
             assert got[i].tobytes() == want, (op, i)
-    prod = ctx.field_op_vec(k16.FQ2N, k16.OP_MUL, a[:1], b[:1])[0]
+    prod = ctx.field_op_vec(selv, k16.OP_MUL, a[:1], b[:1])[0]
     assert prod[:4].tobytes() == bytes(32) and prod[4:].tobytes() == mont(12).tobytes()
 
 
-@pytest.mark.parametrize("sel,group", [("G1_ENG9", 0), ("G2_ENG2N", 1)])
+@pytest.mark.parametrize("sel,group", [("G1_ENG9", 0), ("G2_ENG2N", 1), ("G2_PAIR", 1)])
 def test_point_ops_hot_path_formulas(ctx, sel, group):
     """padd9 / padd_mixed9 / pdbl9 (G1) and the Fq2n instantiation of the XYZZ templates (G2) -- the formulas the bucket
     accumulation, fold and reduction kernels execute -- against the oracle, XYZZ representation for every branch of
