@@ -199,28 +199,37 @@ static int sharded_run(k16_msm_shards* s, const void* h_scalars, const void* con
         const uint64_t cnt = sh.hi - sh.lo;
         const size_t   r   = (size_t)(&sh - s->shards.data());
         const void*    ds  = d_scalars ? d_scalars[r] : sh.d_scalars;
-        int            rc2 = K16_OK;
-        if (cnt && !d_scalars) rc2 = k16_h2d(sh.ctx, sh.d_scalars, (const char*)h_scalars + sh.lo * 32, (size_t)cnt * 32);
-        if (rc2) return rc2;
-        // one device's share: k16_msm's own path -- above 2^24 rows, chunks on two lanes + fold (msm_api.hip)
-        if (cnt <= (1ull << 24)) {
-            rc2 = k16_msm_enqueue_prepared(sh.ctx, s->group, sh.d_bases, ds, cnt);
+        const size_t   pb  = aff_bytes(s->group);
+        // One device call takes up to 2^24 rows (msm_api.hip); scalars that arrive in HOST memory are uploaded in pieces of
+        // 2^22 rows (128 MB) so that piece i + 1 crosses PCIe while piece i is sorted and accumulated: the uploads go through
+        // the context's stream (lane 0), the MSMs alternate between lanes 1 and 2.  The pieces' partial results are folded
+        // like the shards' (one XYZZ point each).
+        const uint64_t CH = d_scalars ? (1ull << 24) : (1ull << 22);
+        if (cnt <= CH) {
+            int rc2 = K16_OK;
+            if (cnt && !d_scalars) rc2 = k16_h2d(sh.ctx, sh.d_scalars, (const char*)h_scalars + sh.lo * 32, (size_t)cnt * 32);
+            if (!rc2) rc2 = k16_msm_enqueue_prepared(sh.ctx, s->group, sh.d_bases, ds, cnt);
             if (!rc2) rc2 = k16_msm_finish(sh.ctx, parts.data() + r * xb, nullptr);
             return rc2;
         }
-        const size_t   pb     = aff_bytes(s->group);
-        const uint64_t CH     = 1ull << 24, chunks = (cnt + CH - 1) / CH;
+        const uint64_t             chunks = (cnt + CH - 1) / CH;
         std::vector<unsigned char> cp((size_t)chunks * xb);
-        uint64_t       enq = 0, fin = 0;
-        auto           next = [&]() -> int {
+        uint64_t                   enq = 0, fin = 0;
+        int                        rc2 = K16_OK;
+        auto                       next = [&]() -> int {
             const uint64_t lo = enq * CH, c = std::min<uint64_t>(CH, cnt - lo);
-            (void)k16_msm_set_lane(sh.ctx, (int)(enq % 2));
+            if (!d_scalars) {
+                const int e = k16_h2d(sh.ctx, (char*)sh.d_scalars + lo * 32, (const char*)h_scalars + (sh.lo + lo) * 32, (size_t)c * 32);
+                if (e) return e;
+            }
+            (void)k16_msm_set_lane(sh.ctx, d_scalars ? (int)(enq % 2) : 1 + (int)(enq % 2));
             enq++;
             return k16_msm_enqueue_prepared(sh.ctx, s->group, (const char*)sh.d_bases + lo * pb, (const char*)ds + lo * 32, c);
         };
         rc2 = next();
         while (!rc2 && fin < chunks) {
-            if (enq < chunks) rc2 = next();
+            if (enq < chunks) rc2 = next();                                  // upload + enqueue the next piece ...
+            if (!rc2 && enq < chunks && enq - fin < 3) rc2 = next();         // ... and one more (two MSMs + one upload in flight)
             if (!rc2) rc2 = k16_msm_finish(sh.ctx, cp.data() + (size_t)fin * xb, nullptr);
             fin++;
         }
