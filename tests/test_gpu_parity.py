@@ -853,6 +853,79 @@ def test_msm_with_hip_graphs_option(ctx):
         d.free()
 
 
+def test_masked_sorts_never_replay_another_masks_graph(ctx):
+    """a captured sort has its kernels' arguments baked in and its key names neither the zero-row mask nor the
+    row indirection.  With K16_OPT_GRAPHS on, the SAME scalar array enqueued with mask A, with mask B, and with no mask
+    must each give ITS sum (masked sorts are launched eagerly); a mask that hides rows whose points are not (0,0) makes the
+    difference visible: every expected value below differs from the others."""
+    import k16
+    n = 1 << 16                      # the staged / partition sort
+    bases = ol.gen_points(0, 21, n)
+    sc = np_scalars(811, n, "uniform")
+    d_b = ctx.to_device(bases)
+    prep = ctx.bases_prepare(k16.G1, d_b, n)
+    d_s = ctx.to_device(sc)
+
+    def mask_of(hidden):
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        for i in hidden:
+            bits[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+        return ctx.to_device(bits), hidden
+
+    def want(hidden):
+        b = bases.copy()
+        b[list(hidden)] = 0          # a hidden row contributes nothing
+        return ol.msm(0, b, sc, nthreads=8)[1]
+
+    ma, mb = mask_of(range(0, 4000, 3)), mask_of(range(1, 9000, 7))
+    w_a, w_b, w_none = want(ma[1]), want(mb[1]), want([])
+    assert len({w_a, w_b, w_none}) == 3
+    ctx.set_option(k16.OPT_GRAPHS, 1)
+    try:
+        for rep in range(4):         # eager, capture, replay, replay
+            for m, w in ((None, w_none), (ma[0], w_a), (mb[0], w_b), (None, w_none), (mb[0], w_b), (ma[0], w_a)):
+                if m is not None:
+                    ctx.msm_set_zero_row_mask(m)
+                ctx.msm_enqueue_prepared(k16.G1, prep, d_s, n)
+                assert ctx.msm_finish(k16.G1)[1] == w, rep
+    finally:
+        ctx.set_option(k16.OPT_GRAPHS, 0)
+    for d in (d_b, prep, d_s, ma[0], mb[0]):
+        d.free()
+
+
+def test_one_shot_requests_do_not_outlive_an_enqueue_that_returns_early(ctx):
+    """a zero-row mask (or a sort-reuse request) set for the NEXT enqueue covers exactly one enqueue -- also one
+    that returns early (n = 0, an argument error): the MSM after it must see every row."""
+    import k16
+    n = 1 << 16
+    bases = ol.gen_points(0, 33, n)
+    sc = np_scalars(812, n, "uniform")
+    d_b = ctx.to_device(bases)
+    prep = ctx.bases_prepare(k16.G1, d_b, n)
+    d_s = ctx.to_device(sc)
+    full = ol.msm(0, bases, sc, nthreads=8)[1]
+    bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+    bits[:200] = np.uint64(0xFFFFFFFFFFFFFFFF)          # hides 12 800 real points
+    d_m = ctx.to_device(bits)
+    # (1) n = 0 consumes the mask
+    ctx.msm_set_zero_row_mask(d_m)
+    ctx.msm_enqueue_prepared(k16.G1, prep, d_s, 0)
+    x0, _ = ctx.msm_finish(k16.G1)
+    assert ol.pt_eq(0, x0, ol.mul_scalar(0, ol.generator(0), pm.limbs(0)))
+    ctx.msm_enqueue_prepared(k16.G1, prep, d_s, n)
+    assert ctx.msm_finish(k16.G1)[1] == full
+    # (2) an enqueue refused for its arguments consumes it too
+    ctx.msm_set_zero_row_mask(d_m)
+    ctx.msm_sort_from_lane(3)                            # no sort on lane 3: the enqueue fails
+    with pytest.raises(k16.K16Error):
+        ctx.msm_enqueue_prepared(k16.G1, prep, d_s, n)
+    ctx.msm_enqueue_prepared(k16.G1, prep, d_s, n)
+    assert ctx.msm_finish(k16.G1)[1] == full
+    for d in (d_b, prep, d_s, d_m):
+        d.free()
+
+
 @pytest.mark.parametrize("kind", ["uniform", "full256", "witness"])
 def test_msm_g1_2p20_vs_oracle(ctx, kind):
     """BASELINE config 2 at its stated size against the oracle directly (not only through closed forms): 2^20 points,
