@@ -133,7 +133,13 @@ static int for_each_shard(k16_msm_shards* s, F f)
             s->shards[r].rc = K16_ERR_HIP;
         }
     });
-    s->shards[0].rc = f(s->shards[0]);
+    try { // (an exception on the calling thread must not skip the joins: a joinable std::thread's destructor terminates)
+        s->shards[0].rc = f(s->shards[0]);
+    } catch (const std::bad_alloc&) {
+        s->shards[0].rc = K16_ERR_NOMEM;
+    } catch (...) {
+        s->shards[0].rc = K16_ERR_HIP;
+    }
     for (auto& t : th) t.join();
     for (size_t r = 0; r < s->shards.size(); r++) {
         if (s->shards[r].rc) {
