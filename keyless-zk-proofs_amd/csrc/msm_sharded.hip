@@ -124,7 +124,7 @@ template <class F>
 static int for_each_shard(k16_msm_shards* s, F f)
 {
     std::vector<std::thread> th;
-    for (size_t r = 1; r < s->shards.size(); r++) th.emplace_back([s, r, &f]() {
+    auto                     work = [s, &f](size_t r) {
         try {
             s->shards[r].rc = f(s->shards[r]);
         } catch (const std::bad_alloc&) {
@@ -132,7 +132,16 @@ static int for_each_shard(k16_msm_shards* s, F f)
         } catch (...) {
             s->shards[r].rc = K16_ERR_HIP;
         }
-    });
+    };
+    std::vector<size_t> inline_shards; // shards whose thread could not be started (std::system_error): run by the caller
+    th.reserve(s->shards.size());
+    for (size_t r = 1; r < s->shards.size(); r++) {
+        try {
+            th.emplace_back(work, r);
+        } catch (...) {
+            inline_shards.push_back(r);
+        }
+    }
     try { // (an exception on the calling thread must not skip the joins: a joinable std::thread's destructor terminates)
         s->shards[0].rc = f(s->shards[0]);
     } catch (const std::bad_alloc&) {
@@ -140,6 +149,7 @@ static int for_each_shard(k16_msm_shards* s, F f)
     } catch (...) {
         s->shards[0].rc = K16_ERR_HIP;
     }
+    for (size_t r : inline_shards) work(r);
     for (auto& t : th) t.join();
     for (size_t r = 0; r < s->shards.size(); r++) {
         if (s->shards[r].rc) {
