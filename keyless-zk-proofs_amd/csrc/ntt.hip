@@ -373,8 +373,13 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
     if (tail_dst && ctx->tune.ntt_tail_small) tile_log = 10;
     const uint32_t TLMAX = tile_log == 11 ? 1u : 4u;
     while (s0 < logn) {
-        const uint32_t TL = s0 < TLMAX ? s0 : TLMAX;                    // T = min(2^s0, 16) lo values per tile
+        uint32_t       TL = s0 < TLMAX ? s0 : TLMAX;                    // T = min(2^s0, 16) lo values per tile
         const uint32_t K  = std::min<uint32_t>(logn - s0, tile_log - TL); // <= 2^tile_log elements per tile
+        // a SHORT last pass (2^21: stages 17-21, K = 5) fills its tile with more lo values instead of running half-empty: with
+        // T = 16 its tiles had 512 elements -- 128 quads for 256 lanes, so the two double stages of its three rounds ran on
+        // half of the workgroup (the pass sat at 0.60 of its issue bound, profiles/r04/pmc_ntt_passes.txt); T = 32 gives every lane
+        // its four elements and 1 KB runs (round 5)
+        if (TL + K < tile_log && !ctx->tune.ntt_tail_small) TL = std::min<uint32_t>(s0, tile_log - K);
         const bool     first = s0 == 0, last = s0 + K == logn;
         const bool     cin = !packed9 && first, cout = !packed9 && last, tail = tail_dst && last;
         const dim3     grid((unsigned)(n >> (K + TL)), (unsigned)count);
