@@ -214,15 +214,38 @@ __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr
 // bytes): 43 MB for the Keyless circuit, 0.78 ms of PCIe time during which the GPU has nothing to do.  The host (a few
 // threads, witness_pack below) splits it into one byte per wire + a list of the wide values (2.3 MB); this kernel rebuilds
 // the n x 32-byte array in HBM, reading both straight from pinned, device-mapped host memory.  Same bytes as the plain copy.
-__global__ void __launch_bounds__(256) k_wtns_expand_narrow(const uint8_t* __restrict__ narrow, Fr* __restrict__ out, uint32_t n,
+// A grid-stride loop over at most 1024 long-lived ONE-WAVE workgroups: beside another prover's bucket accumulation -- two-wave
+// workgroups at three waves per SIMD, thousands of them pending -- a workgroup of four waves finds room on a CU only when the
+// accumulation's list runs dry, and the one-wire-per-lane version of this kernel (5,200 workgroups of 256) took 1.2-1.4 ms there
+// instead of its 38 us; as one-wave workgroups 0.2 ms (profiles/r05/two_provers_interleaving.log).  One wave rebuilds 256
+// wires per step from ONE 256-byte read of the pinned array (a dword per lane, the next step's issued before this step's
+// stores); the bytes reach the lanes that store them by cross-lane reads, so that every store instruction of a wave covers
+// 2 KB of consecutive HBM.
+__global__ void __launch_bounds__(64) k_wtns_expand_narrow(const uint32_t* __restrict__ narrow4, Fr* __restrict__ out, uint32_t n,
                                                             uint16_t* __restrict__ n16)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint4* d = reinterpret_cast<uint4*>(&out[i]);
-    d[0]     = make_uint4((uint32_t)narrow[i], 0u, 0u, 0u);
-    d[1]     = make_uint4(0u, 0u, 0u, 0u);
-    n16[i]   = narrow[i]; // (k_wtns_expand_wide, behind this kernel on the stream, flags the wide wires)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n_chunks = (n + 255u) / 256u, n_words = (n + 3u) / 4u; // (the array is allocated in whole dwords)
+    uint32_t       c   = wave;
+    uint32_t       nxt = (c < n_chunks && c * 64u + lane < n_words) ? narrow4[c * 64u + lane] : 0u;
+    for (; c < n_chunks; c += n_waves) {
+        const uint32_t cur = nxt;
+        const uint32_t c2  = c + n_waves;
+        if (c2 < n_chunks && c2 * 64u + lane < n_words) nxt = narrow4[c2 * 64u + lane];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t v = (uint32_t)__shfl((int)cur, (int)(k * 16u + (lane >> 2)));
+            const uint32_t b = (v >> (8u * (lane & 3u))) & 0xffu;
+            const uint32_t i = c * 256u + k * 64u + lane;
+            if (i < n) {
+                uint4* d = reinterpret_cast<uint4*>(&out[i]);
+                d[0]     = make_uint4(b, 0u, 0u, 0u);
+                d[1]     = make_uint4(0u, 0u, 0u, 0u);
+                n16[i]   = (uint16_t)b; // (k_wtns_expand_wide, behind this kernel on the stream, flags the wide wires)
+            }
+        }
+    }
 }
 // plain-copy path: the same 16-bit array from the full witness
 __global__ void __launch_bounds__(256) k_wtns_n16(const uint4* __restrict__ wtns, uint32_t n, uint16_t* __restrict__ n16)
@@ -469,7 +492,7 @@ static WitnessPacker* packer_create(k16_ctx* ctx, uint32_t n_vars)
     w->count.assign(T, 0);
     w->overflow.assign(T, 0);
     const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
-    if (hipHostMalloc((void**)&w->h_narrow, n_vars, flags) != hipSuccess ||
+    if (hipHostMalloc((void**)&w->h_narrow, ((size_t)n_vars + 3) & ~(size_t)3, flags) != hipSuccess ||
         hipHostMalloc((void**)&w->h_idx, (size_t)T * w->cap * 4, flags) != hipSuccess ||
         hipHostMalloc((void**)&w->h_val, (size_t)T * w->cap * 32, flags) != hipSuccess ||
         hipHostGetDevicePointer((void**)&w->d_narrow, w->h_narrow, 0) != hipSuccess ||
@@ -978,7 +1001,8 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
             L.count[t] = w->count[t];
             most       = std::max(most, w->count[t]);
         }
-        hipLaunchKernelGGL(k_wtns_expand_narrow, dim3((p->n_vars + 255) / 256), dim3(256), 0, st, w->d_narrow, p->d_wtns, p->n_vars, p->d_n16);
+        hipLaunchKernelGGL(k_wtns_expand_narrow, dim3(std::min<uint32_t>((p->n_vars + 255) / 256, 1024u)), dim3(64), 0, st,
+                           reinterpret_cast<const uint32_t*>(w->d_narrow), p->d_wtns, p->n_vars, p->d_n16);
         if (most)
             hipLaunchKernelGGL(k_wtns_expand_wide, dim3(std::min<uint32_t>((most + 255) / 256, 64), w->n_threads), dim3(256), 0, st, L, p->d_wtns, p->d_n16);
         K16_HIP(ctx, hipGetLastError());
