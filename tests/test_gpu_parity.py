@@ -964,19 +964,21 @@ def test_ntt_large_sizes_vs_oracle(ctx, log2n):
         assert np.array_equal(ctx.ntt(a, max_domain=2 * n, inverse=inverse), ol.ntt(a, max_domain=2 * n, inverse=inverse))
 
 
-def test_compact_witness_upload_edge_cases(tmp_path, monkeypatch):
+@pytest.mark.parametrize("n_vars", [70000, 65539])
+def test_compact_witness_upload_edge_cases(tmp_path, monkeypatch, n_vars):
     """The witness crosses PCIe in compact form for circuits of >= 2^16 wires (prover.hip WitnessPacker / k_wtns_expand_*: one
     byte per wire + per-host-thread lists of the wide values; a list that overflows makes the proof fall back to the plain
     copy).  What the Keyless-shape witnesses never reach: values exactly at the byte boundary and with only a high word set,
     wide values at the first / last wire and across the host threads' range boundaries, a range holding exactly its list
     capacity, one more than that (fallback), and a witness of nothing but wide values.  Every proof must equal the oracle's
-    (RS/groth16.cpp:41-360 reads the same 32-byte values whatever their size)."""
+    (RS/groth16.cpp:41-360 reads the same 32-byte values whatever their size).  65539 wires: the byte array is read a dword per
+    lane, 256 wires per wave step (k_wtns_expand_narrow) -- neither divides the wire count, the last dword is partly padding."""
     import k16
     import zkey_builder as zb
     monkeypatch.setenv("K16_HOST_THREADS", "4")      # four ranges: the capacities below are exact for that split
     c = k16.Context(0)
     try:
-        n_vars, N, n_coefs, T = 70000, 1 << 17, 200000, 4
+        N, n_coefs, T = 1 << 17, 200000, 4
         zk, wt = str(tmp_path / "c.zkey"), str(tmp_path / "c.wtns")
         zb.build_zkey(zk, n_vars, 1, N, n_coefs, seed=31)
         p = k16.Prover(c, zk)
