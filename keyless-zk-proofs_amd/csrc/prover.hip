@@ -1127,6 +1127,8 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
             K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, 2), p->ev_w, 0));
             ctx->cur_lane  = 2;
             ctx->skip_next = skip_b;
+            // (b2_lead: the shared sort contains B's (0,0) rows; B2's accumulation steps over them as it does when it trails)
+            if (b2_lead && !ctx->tune.no_acc_skip && !p->b_derive && p->d_skip_ac) ctx->acc_skip_next = (const uint64_t*)p->d_zmask[2];
             if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, n_wit))) return rc;
         }
         ctx->cur_lane        = 0;

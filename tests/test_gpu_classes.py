@@ -330,7 +330,7 @@ def test_tables_that_share_their_scalars_share_or_derive_the_bucket_sort(ctx, gr
         d.free()
 
 
-@pytest.mark.parametrize("mode", ["classes", "b_sort", "b_derive", "fused_h_scalars"])
+@pytest.mark.parametrize("mode", ["classes", "b_sort", "b_derive", "fused_h_scalars", "b2_first"])
 def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, monkeypatch, mode):
     """BASELINE config 3 at its stated size (nVars 1,343,588, N = 2^21, B1 / B2 half (0,0)) with the witness MSMs taking
     the paths that are off by default -- scalar classes (K16_CLASSES=1), a bucket sort of B's own without its (0,0)
@@ -339,7 +339,7 @@ def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, m
     prover."""
     import bench
     import k16
-    monkeypatch.setenv({"classes": "K16_CLASSES", "b_sort": "K16_B_SORT", "b_derive": "K16_B_DERIVE", "fused_h_scalars": "K16_FUSED_HSCALARS"}[mode], "1")
+    monkeypatch.setenv({"classes": "K16_CLASSES", "b_sort": "K16_B_SORT", "b_derive": "K16_B_DERIVE", "fused_h_scalars": "K16_FUSED_HSCALARS", "b2_first": "K16_B2_FIRST"}[mode], "1")
     n_vars, N, n_coefs = bench.KEYLESS["n_vars"], bench.KEYLESS["domain"], bench.KEYLESS["n_coefs"]
     zk = str(tmp_path / "keyless_shape.zkey")
     wt = str(tmp_path / "keyless_shape.wtns")
