@@ -86,6 +86,32 @@ static int one_case(uint32_t N, uint32_t n_vars, uint64_t n_coefs, const std::ve
         rows_seen++;
     }
     if (rows_seen != 2 * (size_t)N) return 7;
+    // rows of one length follow each other in the order of their output positions (k_spmv stores row c of matrix m at the
+    // bit-reversed index of c; position-major, A before B): the stores of a slice stay within a few KB
+    {
+        uint32_t logN = 0;
+        while ((1ull << logN) < N) logN++;
+        std::vector<uint32_t> len(2 * (size_t)N, 0);
+        for (uint64_t i = 0; i < n_coefs; i++) {
+            uint32_t m, c;
+            memcpy(&m, &cf[i * 44], 4);
+            memcpy(&c, &cf[i * 44 + 4], 4);
+            len[(m == 0 ? 0 : N) + c]++;
+        }
+        auto key = [&](uint32_t row) -> uint64_t {
+            const uint32_t c = row < N ? row : row - N;
+            uint32_t       pos = 0;
+            for (uint32_t b = 0; b < logN; b++) pos |= ((c >> b) & 1u) << (logN - 1 - b);
+            return 2ull * pos + (row < N ? 0 : 1);
+        };
+        uint32_t prev_row = 0xffffffffu;
+        for (size_t q = 0; q < 64ull * plan.n_slices; q++) {
+            const uint32_t row = plan.row_of[q];
+            if (row == 0xffffffffu) continue;
+            if (prev_row != 0xffffffffu && len[prev_row] == len[row] && key(prev_row) >= key(row)) return 10;
+            prev_row = row;
+        }
+    }
     for (size_t r = 0; r < 2 * (size_t)N; r++)
         if (got[r] != want[r]) return 8;
     // padding stays small: at most one slice-worth per distinct length
