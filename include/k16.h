@@ -295,6 +295,24 @@ int  k16_prover_prove_file_timed(k16_prover* p, const char* wtns_path, const uin
 /* witness already in memory: n_vars x 32 B standard form (the payload of wtns section 2) */
 int  k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_std,
                           const uint8_t* s_std, char* out_json, size_t cap, float* device_ms);
+/* Compact witness hand-off (round 5; SURVEY 8(f).1, the step after k16_prover_prove_mem; replaces the file hand-off of
+ * fullprover.cpp:212-224 for a caller that owns its witness calculator).  k16_prover_prove_mem spends its first 0.24 ms scanning
+ * the n_vars x 32-byte witness into the form that crosses PCIe: one byte per wire -- the value when it is below 256, 0
+ * otherwise -- plus the list of the wires that hold larger values (wire number, 32-byte standard-form value; any order, every
+ * such wire exactly once).  A witness calculator produces that form for free while it computes the wires:
+ *   k16_prover_compact_buffers   the prover's pinned, device-mapped upload buffers (valid for the prover's lifetime; written
+ *                                by the caller before every k16_prover_prove_compact): narrow[n_vars], wide_idx[*wide_cap],
+ *                                wide_val[*wide_cap][32].  K16_ERR_ARG for a prover without them (circuits below 2^16 wires).
+ *   k16_prover_prove_compact     proves the witness the buffers hold, n_wide entries of the list being valid: the proof's
+ *                                first kernel starts at once.  Same result, outputs and errors as k16_prover_prove_mem for
+ *                                the same witness; K16_ERR_ARG when n_wide exceeds the list (such a witness goes through
+ *                                k16_prover_prove_mem), K16_ERR_FORMAT for a wire number out of range or a listed wire whose
+ *                                narrow byte is not 0 (checked on the device by the kernel that reads the list: the entry is
+ *                                skipped, the call fails when its device work has been joined).
+ * One proof at a time per prover, as for every prove call; k16_prover_prove_mem / _prove_file overwrite the same buffers. */
+int  k16_prover_compact_buffers(k16_prover* p, uint8_t** narrow, uint32_t** wide_idx, uint8_t** wide_val, uint64_t* wide_cap);
+int  k16_prover_prove_compact(k16_prover* p, uint64_t n_wide, const uint8_t* r_std, const uint8_t* s_std, char* out_json,
+                              size_t cap, float* device_ms);
 /* The drop-in FullProver (include/k16_fullprover.hpp) with the witness in memory: `fullprover` points to a FullProver object
  * (the one the Rust crate holds; its pool of provers -- K16_DEVICES -- serves concurrent callers), wtns_values is the payload
  * of the .wtns file's section 2.  FullProver::prove(path) maps and parses a 43 MB file inside every call; a service that

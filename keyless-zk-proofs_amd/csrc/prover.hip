@@ -261,13 +261,21 @@ struct WideLists {
     const uint4*    val[32]; // 2 x uint4 per value
     uint32_t        count[32];
     uint32_t        n_lists;
+    uint32_t        n_vars;
+    uint32_t*       bad; // pinned, device-mapped: set when an entry names no wire of the circuit, or a wire whose byte is not 0
 };
+// (the lists are the host scan's -- or, through k16_prover_prove_compact, the CALLER's: an entry is checked before it is used,
+// a bad one is skipped and reported when the proof's device work has been joined)
 __global__ void __launch_bounds__(256) k_wtns_expand_wide(WideLists L, Fr* __restrict__ out, uint16_t* __restrict__ n16)
 {
     const uint32_t t = blockIdx.y;
     if (t >= L.n_lists) return;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < L.count[t]; j += gridDim.x * blockDim.x) {
         const uint32_t i = L.idx[t][j];
+        if (i >= L.n_vars || n16[i] != 0) {
+            atomicOr(L.bad, i >= L.n_vars ? 1u : 2u);
+            continue;
+        }
         uint4*         d = reinterpret_cast<uint4*>(&out[i]);
         d[0]     = L.val[t][2 * j];
         d[1]     = L.val[t][2 * j + 1];
@@ -424,6 +432,8 @@ struct WitnessPacker {
     uint8_t*              d_narrow  = nullptr;
     uint32_t*             d_idx     = nullptr;
     uint8_t*              d_val     = nullptr;
+    uint32_t*             h_bad     = nullptr; // pinned: k_wtns_expand_wide's report of a bad list entry (see WideLists)
+    uint32_t*             d_bad     = nullptr;
     uint32_t              cap       = 0; // wide values a range's region holds (a quarter of the range: beyond that, plain copy)
     std::vector<uint32_t> count;
     std::vector<uint8_t>  overflow;
@@ -474,6 +484,7 @@ struct WitnessPacker {
         if (h_narrow) (void)hipHostFree(h_narrow);
         if (h_idx) (void)hipHostFree(h_idx);
         if (h_val) (void)hipHostFree(h_val);
+        if (h_bad) (void)hipHostFree(h_bad);
     }
 };
 static WitnessPacker* packer_create(k16_ctx* ctx, uint32_t n_vars)
@@ -495,6 +506,8 @@ static WitnessPacker* packer_create(k16_ctx* ctx, uint32_t n_vars)
     if (hipHostMalloc((void**)&w->h_narrow, ((size_t)n_vars + 3) & ~(size_t)3, flags) != hipSuccess ||
         hipHostMalloc((void**)&w->h_idx, (size_t)T * w->cap * 4, flags) != hipSuccess ||
         hipHostMalloc((void**)&w->h_val, (size_t)T * w->cap * 32, flags) != hipSuccess ||
+        hipHostMalloc((void**)&w->h_bad, 64, flags) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&w->d_bad, w->h_bad, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&w->d_narrow, w->h_narrow, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&w->d_idx, w->h_idx, 0) != hipSuccess ||
         hipHostGetDevicePointer((void**)&w->d_val, w->h_val, 0) != hipSuccess) {
@@ -908,17 +921,19 @@ static inline int fault_injected_now() { return 0; }
 #endif
 
 int k16_msm_classified_phase(k16_ctx* ctx, int group, const void* d_prepared, const k16_scalar_classes* cls, int set, int phase);
-static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
-                           char* out_json, size_t cap, float* device_ms);
+// prepacked >= 0: the compact hand-off (k16_prover_prove_compact) -- h_wtns is null, the caller has filled the packer's pinned
+// buffers and `prepacked` entries of its wide-value list
+static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, int64_t prepacked, const uint8_t* r_in,
+                           const uint8_t* s_in, char* out_json, size_t cap, float* device_ms);
 
-extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in,
-                                    const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
+static int prove_guarded(k16_prover* p, const void* h_wtns, uint64_t n_vars, int64_t prepacked, const uint8_t* r_in,
+                         const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
 {
     return k16_guard((p ? p->ctx : nullptr), [&]() -> int {
-    if (!p || !h_wtns || !out_json) return K16_ERR_ARG;
+    if (!p || (!h_wtns && prepacked < 0) || !out_json) return K16_ERR_ARG;
     int rc;
     try {
-        rc = prove_mem_inner(p, h_wtns, n_vars, r_in, s_in, out_json, cap, device_ms);
+        rc = prove_mem_inner(p, h_wtns, n_vars, prepacked, r_in, s_in, out_json, cap, device_ms);
     } catch (const std::bad_alloc&) {
         rc = K16_ERR_NOMEM;
         try {
@@ -951,8 +966,55 @@ extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t 
     });
 }
 
-static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in, const uint8_t* s_in,
-                           char* out_json, size_t cap, float* device_ms)
+extern "C" int k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, const uint8_t* r_in,
+                                    const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
+{
+    if (!h_wtns) return K16_ERR_ARG;
+    return prove_guarded(p, h_wtns, n_vars, -1, r_in, s_in, out_json, cap, device_ms);
+}
+
+// ---- compact witness hand-off (include/k16.h; SURVEY 8(f).1, the step after prove_mem).  What k16_prover_prove_mem spends its
+// first 0.24 ms on -- scanning the 43 MB witness into one byte per wire + the list of the wide values (WitnessPacker) -- is
+// work a witness calculator does for free while it computes the wires: it writes the compact form straight into the prover's
+// pinned, device-mapped upload buffers and the proof's first kernel starts at once.
+extern "C" int k16_prover_compact_buffers(k16_prover* p, uint8_t** narrow, uint32_t** wide_idx, uint8_t** wide_val,
+                                          uint64_t* wide_cap)
+{
+    if (!p || !narrow || !wide_idx || !wide_val || !wide_cap) return K16_ERR_ARG;
+    if (!p->packer) {
+        try {
+            p->ctx->err = "compact hand-off: this prover uploads its witness plainly (fewer than 2^16 wires, or no host pool)";
+        } catch (...) {
+        }
+        return K16_ERR_ARG;
+    }
+    *narrow   = p->packer->h_narrow;
+    *wide_idx = p->packer->h_idx;
+    *wide_val = p->packer->h_val;
+    *wide_cap = (uint64_t)p->packer->n_threads * p->packer->cap; // (the scan's per-range regions are one contiguous list here)
+    return K16_OK;
+}
+
+extern "C" int k16_prover_prove_compact(k16_prover* p, uint64_t n_wide, const uint8_t* r_in, const uint8_t* s_in, char* out_json,
+                                        size_t cap, float* device_ms)
+{
+    if (!p || !out_json) return K16_ERR_ARG;
+    WitnessPacker* w = p->packer;
+    if (!w || n_wide > (uint64_t)w->n_threads * w->cap) {
+        try {
+            p->ctx->err = w ? "compact hand-off: more wide values than the list holds (use k16_prover_prove_mem)"
+                            : "compact hand-off: this prover uploads its witness plainly";
+        } catch (...) {
+        }
+        return K16_ERR_ARG;
+    }
+    // (the list's entries are checked by the kernel that reads them, k_wtns_expand_wide: a host loop over 27,000 entries and
+    // their bytes costs more than the scan this entry point saves)
+    return prove_guarded(p, nullptr, p->n_vars, (int64_t)n_wide, r_in, s_in, out_json, cap, device_ms);
+}
+
+static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, int64_t prepacked, const uint8_t* r_in,
+                           const uint8_t* s_in, char* out_json, size_t cap, float* device_ms)
 {
     k16_ctx* ctx = p->ctx;
     if (n_vars < p->n_vars) { // the reference does not check; reading past the buffer is not an option here
@@ -989,17 +1051,22 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     };
     K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     int64_t n_wide = -1; // wide (>= 256) witness values, counted on the host: the classification then needs no round trip
-    if (p->packer && p->packer->pack(h_wtns)) {
+    if (p->packer && (prepacked >= 0 || p->packer->pack(h_wtns))) {
         WitnessPacker* w = p->packer;
-        n_wide           = (int64_t)w->wide_total();
+        n_wide           = prepacked >= 0 ? prepacked : (int64_t)w->wide_total();
         WideLists      L;
         L.n_lists = w->n_threads;
+        L.n_vars  = p->n_vars;
+        L.bad     = w->d_bad;
+        *w->h_bad = 0;
         uint32_t most = 0;
         for (unsigned t = 0; t < w->n_threads; t++) {
             L.idx[t]   = w->d_idx + (size_t)t * w->cap;
             L.val[t]   = reinterpret_cast<const uint4*>(w->d_val + (size_t)t * w->cap * 32);
-            L.count[t] = w->count[t];
-            most       = std::max(most, w->count[t]);
+            // (compact hand-off: ONE list of `prepacked` entries laid over the regions, which are contiguous)
+            L.count[t] = prepacked >= 0 ? (uint32_t)std::min<int64_t>(w->cap, std::max<int64_t>(0, prepacked - (int64_t)t * w->cap))
+                                        : w->count[t];
+            most       = std::max(most, L.count[t]);
         }
         hipLaunchKernelGGL(k_wtns_expand_narrow, dim3(std::min<uint32_t>((p->n_vars + 255) / 256, 1024u)), dim3(64), 0, st,
                            reinterpret_cast<const uint32_t*>(w->d_narrow), p->d_wtns, p->n_vars, p->d_n16);
@@ -1261,6 +1328,11 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, c
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
+    if (p->packer && *p->packer->h_bad) { // (every MSM of this proof has been consumed: nothing is left behind)
+        ctx->err = (*p->packer->h_bad & 1u) ? "compact witness: wire number out of range in the wide-value list"
+                                            : "compact witness: a listed wire must have a zero byte in the narrow array";
+        return K16_ERR_FORMAT;
+    }
     pi_c = h_add(pi_c, pih);
 
     ht("device joined");

@@ -39,7 +39,7 @@ SYMBOLS = [
     "k16_msm_zero_row_mask", "k16_msm_set_zero_row_mask", "k16_msm_sort_from_lane", "k16_scalar_classes_create", "k16_scalar_classes_destroy", "k16_scalar_classes_build", "k16_scalar_classes_counts", "k16_msm_enqueue_classified",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
     "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
-    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_fullprover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
+    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_compact_buffers", "k16_prover_prove_compact", "k16_fullprover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
     "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_verify_coop_gt", "k16_pairing_vec",
     "k16_msm_sharded_create", "k16_msm_sharded_destroy", "k16_msm_sharded_count", "k16_msm_sharded_range", "k16_msm_sharded_ctx",
     "k16_msm_sharded_last_error", "k16_msm_sharded_set_bases", "k16_msm_sharded_set_bases_device", "k16_msm_sharded_run",
@@ -121,6 +121,8 @@ def load():
     L.k16_prover_prove_file.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
     L.k16_prover_prove_file_timed.argtypes = [vp, C.c_char_p, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.k16_prover_prove_mem.argtypes = [vp, vp, u64, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
+    L.k16_prover_compact_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+    L.k16_prover_prove_compact.argtypes = [vp, u64, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
     L.k16_prover_last_h.argtypes = [vp, vp]
     L.k16_prover_warmup_status.argtypes = [vp]
     L.k16_vk_create.argtypes = [vp, vp, vp, vp, vp, vp, u32, C.POINTER(vp)]
@@ -436,6 +438,31 @@ class Prover:
         R_ = np.frombuffer(bytes(r), dtype=np.uint8).copy() if r is not None else None
         S_ = np.frombuffer(bytes(s), dtype=np.uint8).copy() if s is not None else None
         rc = self.ctx.L.k16_prover_prove_mem(self.h, _p(wtns), n_vars, _p(R_), _p(S_), buf, 4096, C.byref(ms))
+        if rc < 0:
+            raise K16Error(rc, (self.ctx.L.k16_last_error(self.ctx.h) or b"").decode())
+        self.last_device_ms = ms.value
+        return buf.value.decode()
+
+    def compact_buffers(self):
+        """The prover's pinned upload buffers as numpy views (k16_prover_compact_buffers): narrow[n_vars] uint8,
+        wide_idx[cap] uint32, wide_val[cap, 32] uint8."""
+        a, b, c, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        rc = self.ctx.L.k16_prover_compact_buffers(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(cap))
+        if rc < 0:
+            raise K16Error(rc, (self.ctx.L.k16_last_error(self.ctx.h) or b"").decode())
+        n, k = self.info()["n_vars"], int(cap.value)
+        narrow = np.ctypeslib.as_array((C.c_uint8 * n).from_address(a.value))
+        idx = np.ctypeslib.as_array((C.c_uint32 * k).from_address(b.value))
+        val = np.ctypeslib.as_array((C.c_uint8 * (k * 32)).from_address(c.value)).reshape(k, 32)
+        return narrow, idx, val
+
+    def prove_compact(self, n_wide, r=None, s=None):
+        """k16_prover_prove_compact: the witness is what compact_buffers() holds."""
+        buf = C.create_string_buffer(4096)
+        ms = C.c_float()
+        R_ = np.frombuffer(bytes(r), dtype=np.uint8).copy() if r is not None else None
+        S_ = np.frombuffer(bytes(s), dtype=np.uint8).copy() if s is not None else None
+        rc = self.ctx.L.k16_prover_prove_compact(self.h, int(n_wide), _p(R_), _p(S_), buf, 4096, C.byref(ms))
         if rc < 0:
             raise K16Error(rc, (self.ctx.L.k16_last_error(self.ctx.h) or b"").decode())
         self.last_device_ms = ms.value

@@ -1031,6 +1031,81 @@ def test_compact_witness_upload_edge_cases(tmp_path, monkeypatch, n_vars):
         c.close()
 
 
+def _fill_compact(prover, w):
+    """what a witness calculator would write: one byte per wire (0 for values >= 256) + the list of the wide wires"""
+    narrow, idx, val = prover.compact_buffers()
+    wide = np.flatnonzero(w[:, 1:].any(axis=1))
+    narrow[:] = w[:, 0]
+    narrow[wide] = 0
+    assert len(wide) <= len(idx)
+    idx[:len(wide)] = wide[::-1]                      # any order
+    val[:len(wide)] = w[wide[::-1]]
+    return len(wide)
+
+
+def test_compact_witness_hand_off(tmp_path):
+    """k16_prover_compact_buffers / k16_prover_prove_compact (include/k16.h): the caller writes the witness in the
+    form the device expands -- one byte per wire + the list of the wide values -- into the prover's pinned buffers, and the
+    proof skips the host scan.  Same proof bytes and H scalars as k16_prover_prove_mem and as the oracle (RS/groth16.cpp:41-360)
+    for the same witness; a bad list entry is skipped on the device and fails the proof; a prover that uploads plainly refuses."""
+    import k16
+    import zkey_builder as zb
+    c = k16.Context(0)
+    try:
+        n_vars, N, n_coefs = 70001, 1 << 17, 200000
+        zk, wt = str(tmp_path / "c.zkey"), str(tmp_path / "c.wtns")
+        zb.build_zkey(zk, n_vars, 1, N, n_coefs, seed=37)
+        p = k16.Prover(c, zk)
+        r, s = pm.limbs(pm.SplitMix64(191).below(pm.R)), pm.limbs(pm.SplitMix64(192).below(pm.R))
+        rs = np.random.RandomState(9)
+        for n_wide_target in (0, 1, 1500):
+            w = np.zeros((n_vars, 32), dtype=np.uint8)
+            w[:, 0] = rs.randint(0, 256, size=n_vars)
+            for k, i in enumerate(rs.choice(np.arange(1, n_vars), size=n_wide_target, replace=False)):
+                w[i] = np.frombuffer(pm.limbs(pm.SplitMix64(5000 + k).below(pm.R) | 256), dtype=np.uint8) if k % 7 else \
+                    np.frombuffer(pm.limbs(256 + k), dtype=np.uint8)
+            w[0] = 0
+            w[0, 0] = 1
+            import struct
+            with open(wt, "wb") as fh:
+                sec1 = struct.pack("<I", 32) + pm.limbs(pm.R) + struct.pack("<I", n_vars)
+                fh.write(b"wtns" + struct.pack("<II", 2, 2) + zb._section(1, sec1) + zb._section(2, w.tobytes()))
+            want, h_ref = ol.prove_files(zk, wt, r, s, nthreads=8, want_h=True)
+            n_wide = _fill_compact(p, w)
+            assert n_wide == n_wide_target
+            got = p.prove_compact(n_wide, r, s)
+            assert np.array_equal(p.last_h(), h_ref), n_wide_target
+            assert got == want, n_wide_target
+            assert p.prove_mem(w, r, s) == want          # (overwrites the buffers: refill before the next compact proof)
+        # a bad list entry never reaches the witness array: the proof fails when its device work has been joined
+        narrow, idx, val = p.compact_buffers()
+        n_wide = _fill_compact(p, w)
+        idx[3] = n_vars                                  # wire number out of range
+        with pytest.raises(k16.K16Error) as e:
+            p.prove_compact(n_wide, r, s)
+        assert e.value.rc == -5
+        n_wide = _fill_compact(p, w)
+        narrow[idx[5]] = 7                               # a listed wire with a byte of its own
+        with pytest.raises(k16.K16Error) as e:
+            p.prove_compact(n_wide, r, s)
+        assert e.value.rc == -5
+        with pytest.raises(k16.K16Error) as e:
+            p.prove_compact(len(idx) + 1, r, s)          # more than the list holds
+        assert e.value.rc == -3
+        n_wide = _fill_compact(p, w)
+        assert p.prove_compact(n_wide, r, s) == want     # and the prover is fine afterwards
+        p.close()
+        # a small circuit uploads plainly: no compact buffers
+        zb.build_zkey(zk, 300, 1, 512, 900, seed=38)
+        p2 = k16.Prover(c, zk)
+        with pytest.raises(k16.K16Error) as e:
+            p2.compact_buffers()
+        assert e.value.rc == -3
+        p2.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("field,sel", [(0, "FQ9"), (1, "FR9")])
 def test_lazy_limb_butterfly_forms(ctx, field, sel):
     """fadd9_lazy / fsub9_lazy4_t (bn254_fq9.h): the NTT double stage keeps the sums and differences of its first stage
