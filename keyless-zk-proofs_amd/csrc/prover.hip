@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256) k_wtns_expand_wide(WideLists L, Fr* __res
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < L.count[t]; j += gridDim.x * blockDim.x) {
         const uint32_t i = L.idx[t][j];
         if (i >= L.n_vars || n16[i] != 0) {
-            atomicOr(L.bad, i >= L.n_vars ? 1u : 2u);
+            *(volatile uint32_t*)L.bad = i >= L.n_vars ? 1u : 2u; // (a plain store: no PCIe atomic needed; any bad entry's code will do)
             continue;
         }
         uint4*         d = reinterpret_cast<uint4*>(&out[i]);
