@@ -527,6 +527,271 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------- BASELINE configs 4 and 5
+def _tag(dist):
+    return os.environ.get("MASTER_PORT", str(os.getpid())) if dist is not None else str(os.getpid())
+
+
+def make_rank_exchange(dist, ctx, sharding):
+    """The library's RCCL leg (k16_rank_comm_*) on every rank or on none; (exchange, note).  Real RCCL refuses two ranks on one
+    device, so the one-GPU test rig (K16_BENCH_SHARE_GPU) gets it only over the test double named by K16_RCCL_LIB."""
+    import torch
+    if dist is None or os.environ.get("K16_BENCH_EXCHANGE", "c") != "c" or (SHARE_GPU and not os.environ.get("K16_RCCL_LIB")):
+        return None, None
+    ex, note = None, None
+    try:
+        ex = sharding.RankExchange(dist, ctx)
+    except Exception as e:
+        note = "C exchange unavailable (%r): torch.distributed all_gather instead" % (e,)
+        print("bench.py: WARNING: " + note, file=sys.stderr, flush=True)
+    ok = torch.tensor([1 if ex is not None else 0], device=XDEV)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
+    if int(ok.item()) == 0 and ex is not None:
+        ex.close()
+        ex = None
+    return ex, note
+
+
+def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
+    """BASELINE config 5: ONE G1 MSM of 2^log2n points (default 2^26: 4 GiB of points, 2 GiB of scalars) cut N ways.
+    N = 1: k16_msm_sharded_* with EIGHT shards over the visible devices (eight contexts on device 0 on a one-GPU box), host-side
+    fold.  N > 1: rank k owns sharding.shard_range(2^log2n, N, k) as a one-shard k16_msm_sharded object on its GPU (the same
+    pieced upload pipeline), and the ranks' partials travel through k16_rank_comm_* -- ONE ncclAllGather issued by libk16.so --
+    and are folded on every rank.  The scalars arrive in HOST memory inside every run (Curve::multiMulByScalar's contract,
+    curve.hpp:209-215 / multiexp.cpp:183-245); `device_scalars` is the same MSM with the scalars already resident.
+    Checked against the closed form sum_i s_i (i+1) * G over ALL ranks' rows."""
+    total = 1 << log2n
+    lo, hi = sharding.shard_range(total, world, rank)
+    n = hi - lo
+    t0 = time.time()
+    scalars = fast_scalars(n, seed=0x2626 + rank)
+    t_scal = time.time() - t0
+    if world == 1:
+        ndev = max(1, k16.load().k16_device_count())
+        devices = [r % ndev for r in range(8)]
+    else:
+        devices = [dev]
+    sm = k16.ShardedMsm(devices, k16.G1, n)
+    ex, note = None, None
+    try:
+        t0 = time.time()
+        for r in range(sm.count()):
+            slo, shi = sm.shard_range(r)
+            d = sm.shard_ctx(r).synth_points(k16.G1, lo + slo, shi - slo)
+            sm.set_bases_device(r, d)
+            d.free()
+        t_bases = time.time() - t0
+        ex, note = make_rank_exchange(dist, sm.shard_ctx(0), sharding)
+
+        def fold(xyzz):
+            if ex is not None:
+                return ex.exchange_and_fold(k16.G1, xyzz)[0]
+            if dist is not None:
+                return sharding.exchange_and_fold(dist, k16.G1, xyzz, device=None if SHARE_GPU else "cuda")[0]
+            return xyzz
+
+        def timed(run, reps):
+            best = None
+            for _ in range(reps):
+                if dist is not None:
+                    dist.barrier()
+                t1 = time.perf_counter()
+                xyzz = run()
+                t2 = time.perf_counter()
+                res = fold(xyzz)
+                t3 = time.perf_counter()
+                if dist is not None:
+                    dist.barrier()
+                t4 = time.perf_counter()
+                cur = {"total_ms": (t4 - t1) * 1e3, "shard_ms": (t2 - t1) * 1e3, "exchange_and_fold_ms": (t3 - t2) * 1e3,
+                       "one_process_fold_ms": sm.last_ms()["fold_ms"]}
+                if dist is not None:
+                    t = torch.tensor([cur["total_ms"], cur["shard_ms"], cur["exchange_and_fold_ms"]], dtype=torch.float64, device=XDEV)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    cur["total_ms"], cur["shard_ms"], cur["exchange_and_fold_ms"] = (float(v) for v in t.tolist())
+                if best is None or cur["total_ms"] < best["total_ms"]:
+                    best = cur
+            return res, best
+
+        sm.run(scalars)                                   # warm-up: the lanes' workspaces
+        res_host, host = timed(lambda: sm.run(scalars)[0], 3)
+        ds = []
+        for r in range(sm.count()):
+            slo, shi = sm.shard_range(r)
+            ds.append(sm.shard_ctx(r).to_device(scalars[slo:shi]))
+        res_dev, devt = timed(lambda: sm.run_device(ds)[0], 3)
+        for d in ds:
+            d.free()
+        t0 = time.time()
+        k_mine = weighted_sum_mod_r(scalars, lo)
+        t_check = time.time() - t0
+        ranks_seen = 1
+        if dist is not None:
+            ranks_seen = dist.get_world_size()
+            ks = [None] * ranks_seen
+            dist.all_gather_object(ks, k_mine)
+            k_all = sum(ks) % R_MOD
+        else:
+            k_all = k_mine
+        out = None
+        if rank == 0:
+            want = scalar_times_g(sm.shard_ctx(0), k16, k_all)
+            ok = [bool(k16.points_sum(k16.G1, np.frombuffer(x, dtype=np.uint8).reshape(1, 128))[1] == want) for x in (res_host, res_dev)]
+            out = {"workload": "ONE BN254 G1 MSM of 2^%d points, scalars uniform in [0, 2^253), bases (i+1)*G made on the devices" % log2n,
+                   "entry": ("k16_msm_sharded_run: %d shards, one process, host-side EC-add fold" % sm.count()) if world == 1 else
+                            ("k16_msm_sharded_run per rank (1 shard) + %s" %
+                             ("k16_rank_comm_allgather_fold (ONE ncclAllGather issued by libk16.so)" if ex is not None else
+                              "torch.distributed all_gather (gloo test rig)" if SHARE_GPU else "torch.distributed all_gather (RCCL)")),
+                   "ranks_seen": ranks_seen, "shards": sm.count() * ranks_seen, "devices": devices if world == 1 else "one per rank",
+                   "host_scalars": dict(host, points_per_s=total / (host["total_ms"] * 1e-3),
+                                        note="scalars handed over in pageable host memory inside every run (PCIe-inclusive)"),
+                   "device_scalars": dict(devt, points_per_s=total / (devt["total_ms"] * 1e-3)),
+                   "result_checked": all(ok), "exchange_note": note,
+                   "setup_s": {"scalars": t_scal, "bases_on_device": t_bases, "closed_form_on_host": t_check}}
+            if not all(ok) and not os.environ.get("K16_BENCH_NOCHECK"):
+                raise SystemExit("bench.py: the sharded 2^%d MSM differs from the closed form" % log2n)
+        return out
+    finally:
+        if ex is not None:
+            ex.close()
+        sm.close()
+
+
+def config4_wave_leg(k16, torch, dist, rank, world, dev, wave, scale):
+    """BASELINE config 4: a wave of 64 DISTINCT witnesses of a VALID synthetic key of the Keyless shape (tests/valid_key_builder.py:
+    a trapdoor set-up, so its proofs verify), one prover per GPU, proof j on rank j mod N ("one proof per GPU per wave"), every
+    proof through k16_prover_prove_mem with CSPRNG blinding; then ALL 64 are accepted by ONE k16_verify_batch on rank 0 with
+    their own public inputs and rejected with their neighbours' -- the service's loop, prover_handler.rs:244-345."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import groth16_io as gio
+    import valid_key_builder as vkb
+    ctx = k16.Context(dev)
+    zpath = "/tmp/k16_bench_wave_%s.zkey" % _tag(dist)
+    meta = [None]
+    t0 = time.time()
+    if rank == 0:
+        key = vkb.build(lambda g, sc: ctx.synth_points_scalars(g, sc), max(int(1209229 * scale), 64), max(int(107487 * scale), 8),
+                        max(int(26870 * scale), 8), seed=11)
+        with open(zpath + ".part", "wb") as f:
+            f.write(key["zkey"])
+        os.replace(zpath + ".part", zpath)
+        meta = [{k: key[k] for k in ("shape", "vk", "n_vars", "domain", "n_coefs")}]
+        del key
+    if dist is not None:
+        dist.broadcast_object_list(meta, src=0)
+    meta = meta[0]
+    t_key = time.time() - t0
+    prover, others, V = None, [], None
+    try:
+        prover = k16.Prover(ctx, zpath)
+        mine = [j for j in range(wave) if j % world == rank]
+        t0 = time.time()
+        wits = {j: vkb.fast_witness(meta["shape"], 5000 + j) for j in mine}
+        t_wit = time.time() - t0
+        for j in mine[:2]:
+            prover.prove_mem(wits[j][0])              # warm-up (the clocks; the workspaces exist since create)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        out_js, lat = {}, []
+        t_all = time.perf_counter()
+        for j in mine:
+            t1 = time.perf_counter()
+            out_js[j] = prover.prove_mem(wits[j][0])
+            lat.append((time.perf_counter() - t1) * 1e3)
+        elapsed = time.perf_counter() - t_all
+        inputs = {j: wits[j][1] for j in mine}
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=XDEV)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            allv = [None] * world
+            dist.all_gather_object(allv, (out_js, inputs, lat))
+            out_js, inputs, lat = {}, {}, []
+            for a, b, c in allv:
+                out_js.update(a)
+                inputs.update(b)
+                lat += c
+        # one GPU, throughput mode: the same wave through TWO provers that share the device and ONE resident key
+        # (k16_prover_create_shared -- what FullProver builds for K16_DEVICES=0,0)
+        two = None
+        if world == 1 and int(os.environ.get("K16_BENCH_PROVERS", "2")) > 1:
+            import threading
+            c2 = k16.Context(dev)
+            t0 = time.time()
+            p2 = k16.Prover(c2, zpath, share_key_of=prover)
+            t_shared = time.time() - t0
+            others = [(p2, c2)]
+            for c in (ctx, c2):
+                c.set_option(k16.OPT_SHARED_GPU, 1)
+            p2.prove_mem(wits[0][0])
+            jobs, lock, lat2, js2 = list(range(wave)), threading.Lock(), [], {}
+
+            def worker(pv):
+                while True:
+                    with lock:
+                        if not jobs:
+                            return
+                        j = jobs.pop(0)
+                    t1 = time.perf_counter()
+                    js2[j] = pv.prove_mem(wits[j][0])
+                    lat2.append((time.perf_counter() - t1) * 1e3)
+
+            t_all = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(pv,)) for pv in (prover, p2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            el2 = time.perf_counter() - t_all
+            ctx.set_option(k16.OPT_SHARED_GPU, 0)
+            two = {"provers": 2, "shared_resident_key": True, "second_prover_create_s": t_shared, "proofs_per_s": wave / el2,
+                   "p50_ms": float(np.median(lat2)), "p99_ms": float(np.percentile(lat2, 99)), "_proofs": js2}
+        out = None
+        if rank == 0:
+            V = k16.VerifyingKey(ctx, meta["vk"])
+            order = list(range(wave))
+            proofs = [gio.proof_from_json(out_js[j]) for j in order]
+            ins = [inputs[j] for j in order]
+            V.verify_batch(proofs[:2], ins[:2])               # warm-up of the verifier kernels
+            t1 = time.perf_counter()
+            ok = V.verify_batch(proofs, ins)
+            t_verify = time.perf_counter() - t1
+            wrong = V.verify_batch(proofs, [ins[(j + 1) % wave] for j in order])
+            distinct = len(set(proofs)) == wave and len({tuple(x) for x in ins}) == wave
+            out = {"workload": "wave of %d distinct witnesses, valid synthetic Keyless-shape key (nVars %d, N 2^%d, %d coefficients); "
+                               "proof j on rank j mod N" % (wave, meta["n_vars"], int(np.log2(meta["domain"])), meta["n_coefs"]),
+                   "entry": "k16_prover_prove_mem (CSPRNG blinding), one prover per GPU; k16_verify_batch of the whole wave on rank 0",
+                   "ranks_seen": world, "proofs": wave, "proofs_per_s": wave / elapsed, "wave_s": elapsed,
+                   "p50_ms": float(np.median(lat)), "p99_ms": float(np.percentile(lat, 99)),
+                   "verify_wave_ms": t_verify * 1e3, "all_accepted": bool(all(ok)), "wrong_inputs_rejected": not any(wrong),
+                   "distinct": bool(distinct), "proofs_per_s_proved_and_verified": wave / (elapsed + t_verify),
+                   "setup_s": {"build_valid_key": t_key, "witnesses": t_wit}}
+            if two is not None:
+                pr2 = [gio.proof_from_json(two.pop("_proofs")[j]) for j in order]
+                two["all_accepted"] = bool(all(V.verify_batch(pr2, ins)))
+                out["two_provers_one_gpu"] = two
+                if not two["all_accepted"]:
+                    raise SystemExit("bench.py: a proof of the two-prover wave was rejected")
+            if not (all(ok) and not any(wrong) and distinct):
+                raise SystemExit("bench.py: config 4 wave: a proof was rejected (or accepted with a foreign input)")
+        return out
+    finally:
+        if V is not None:
+            V.close()
+        for pv, c in others:
+            pv.close()
+            c.close()
+        if prover is not None:
+            prover.close()
+        ctx.close()
+        if dist is not None:
+            dist.barrier()          # nobody is still opening the key
+        if rank == 0 and os.path.exists(zpath):
+            os.unlink(zpath)
+
+
 # ---------------------------------------------------------------------------------------------------- launch
 def spawn_ranks(args):
     """--gpus N > 1 without a torchrun environment: start the N ranks as a child process.  Called before torch or the
@@ -714,6 +979,9 @@ def main():
     # (round-robin; on a one-GPU box k contexts on device 0), scalars handed over in HOST memory every step
     shards_obj, shard_devices = None, []
     if strong and world == 1 and int(os.environ.get("K16_BENCH_SHARDS", "0")) > 0:
+        if os.environ.get("K16_BENCH_PREPARED") or os.environ.get("K16_BENCH_FIXED_BASE"):
+            sys.exit("bench.py: K16_BENCH_SHARDS does not combine with K16_BENCH_PREPARED / K16_BENCH_FIXED_BASE "
+                     "(the shards hold their own prepared slices; the main context has no table)")
         ndev = max(1, k16.load().k16_device_count())
         shard_devices = [r % ndev for r in range(int(os.environ["K16_BENCH_SHARDS"]))]
     if strong:
@@ -766,21 +1034,26 @@ def main():
     # mode's per-step exchange stays on torch.distributed's asynchronous all_gather, which it overlaps with the next step.
     # K16_BENCH_EXCHANGE=c|torch overrides; a C leg that cannot start (no RCCL library) falls back and says so.
     c_exchange, c_exchange_note = None, None
-    want_c = os.environ.get("K16_BENCH_EXCHANGE", "c" if strong else "torch") == "c"
-    if dist is not None and want_c and not SHARE_GPU:
-        try:
-            c_exchange = sharding.RankExchange(dist, ctx)
-        except Exception as e:
-            c_exchange_note = "C exchange unavailable (%r): torch.distributed all_gather instead" % (e,)
-        ok = torch.tensor([1 if c_exchange is not None else 0], device=XDEV)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # all ranks or none
-        if int(ok.item()) == 0 and c_exchange is not None:
-            c_exchange.close()
-            c_exchange = None
+    # Round 6: the library's own RCCL leg (k16_rank_comm_*: ncclAllGather issued by libk16.so) is the default carrier in BOTH
+    # modes -- what SCALE measures is then the path a C++ service has.  Weak mode keeps its overlap: k16_rank_comm_allgather_start
+    # enqueues step k's exchange, _finish completes step k - 1's.  K16_BENCH_EXCHANGE=torch selects torch.distributed's
+    # all_gather; a C leg that cannot start on every rank falls back to it LOUDLY (stderr + `exchange_note`).  On the one-GPU
+    # test rig (K16_BENCH_SHARE_GPU) real RCCL refuses two ranks per device: the C leg runs there only over the test double
+    # (K16_RCCL_LIB = tests/cpp/fake_rccl.cpp).
+    c_exchange, c_exchange_note = make_rank_exchange(dist, ctx, sharding)
+
+    c_in_flight = [0]
 
     def exchange(xyzz):
         if c_exchange is not None:
-            return c_exchange.exchange_and_fold(k16.G1, xyzz)[0]
+            if strong:
+                return c_exchange.exchange_and_fold(k16.G1, xyzz)[0]
+            c_exchange.start(k16.G1, xyzz)        # this step's gather runs under the next step's GPU work ...
+            c_in_flight[0] += 1
+            if c_in_flight[0] > 1:                # ... and the previous step's is completed and folded now
+                c_in_flight[0] -= 1
+                return c_exchange.finish()[0]
+            return xyzz
         if dist is not None:
             # the path's one exchange: start this step's all_gather, complete the previous step's (it ran under the
             # GPU work enqueued in between); run() drains the last one inside the timed region
@@ -855,6 +1128,9 @@ def main():
                 raise failed[0]
         while pending_x:
             res, _ = sharding.exchange_finish(pending_x.pop(0))
+        while c_in_flight[0]:                     # the last step's exchange, inside the timed region
+            c_in_flight[0] -= 1
+            res = c_exchange.finish()[0]
         return res
 
     step_times = [] if os.environ.get("K16_BENCH_TRACE") else None   # diagnostics: completion time of every step
@@ -869,8 +1145,23 @@ def main():
     if args.warmup:
         run(args.warmup)
 
-    ctx.stats_enable(2)   # HIP events around the dominant kernel only (2 per MSM): the timed region stays lean
-    ctx.stats_reset()
+    # the contexts whose kernels this run times: the main one, or (K16_BENCH_SHARDS) the shards' -- the main context runs no MSM then
+    stat_ctxs = [ctx] if shards_obj is None else [shards_obj.shard_ctx(r) for r in range(shards_obj.count())]
+
+    def stats_enable(v):
+        for c in stat_ctxs:
+            c.stats_enable(v)
+
+    def stats_reset():
+        for c in stat_ctxs:
+            c.stats_reset()
+
+    def stats_get(name):
+        got = [c.stats_get(name) for c in stat_ctxs]
+        return sum(g[0] for g in got), sum(g[1] for g in got)
+
+    stats_enable(2)   # HIP events around the dominant kernel only (2 per MSM): the timed region stays lean
+    stats_reset()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -886,23 +1177,23 @@ def main():
               file=sys.stderr, flush=True)
         print("[bench trace] enqueue ms (all steps incl. warm-up): " + " ".join("%.2f" % v for v in enq_times),
               file=sys.stderr, flush=True)
-    launches, acc_ms = ctx.stats_get("msm_accumulate")
+    launches, acc_ms = stats_get("msm_accumulate")
     # host side of one step (C entry points only): launches, waiting for the GPU, conversion + Horner
-    host_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
+    host_ms = {k: stats_get(k)[1] / max(stats_get(k)[0], 1)
                for k in ("host_enqueue", "host_finish_wait", "host_finish_combine", "host_enqueue_max")}
     # the same kernel without a neighbour on the GPU (one MSM at a time), for reference next to the live figure; this
     # untimed pass also times the other stages
-    ctx.stats_enable(1)
-    ctx.stats_reset()
+    stats_enable(1)
+    stats_reset()
     saved_depth = depth_cell[0]
     depth_cell[0] = 1
     lane[0] = 0
     run(1 if chunked else 3)
     depth_cell[0] = saved_depth
-    iso_launches, iso_ms = ctx.stats_get("msm_accumulate")
-    stage_ms = {k: ctx.stats_get(k)[1] / max(ctx.stats_get(k)[0], 1)
+    iso_launches, iso_ms = stats_get("msm_accumulate")
+    stage_ms = {k: stats_get(k)[1] / max(stats_get(k)[0], 1)
                 for k in ("msm_sort", "msm_accumulate", "msm_fold", "msm_reduce")}
-    ctx.stats_enable(0)
+    stats_enable(0)
 
     ranks_seen = 1
     if dist is not None:
@@ -972,13 +1263,41 @@ def main():
         proof = proof_leg(ctx, k16, torch, dist, rank, world, args.proofs,
                           check_with_oracle=(world == 1 and not args.no_cpu_baseline), scale=args.proof_scale)
 
+    # ---- BASELINE configs 4 and 5 as secondary legs of the SAME line, after the timed region (round 6): ON by default so that
+    # the driver's one command records them at every N; K16_BENCH_NO_CONFIG_LEGS=1 (or _NO_WAVE / _NO_2P26) skips them for quick
+    # runs, K16_BENCH_2P26_LOG2N / K16_BENCH_WAVE_SCALE shrink them for the test suite
+    legs = {}
+    no_legs = bool(os.environ.get("K16_BENCH_NO_CONFIG_LEGS"))
+    if not no_legs and not os.environ.get("K16_BENCH_NO_WAVE"):
+        try:
+            legs["config4_wave"] = config4_wave_leg(k16, torch, dist, rank, world, dev, int(os.environ.get("K16_BENCH_WAVE", "64")),
+                                                    float(os.environ.get("K16_BENCH_WAVE_SCALE", "1.0")))
+        except SystemExit:
+            raise
+        except Exception as e:
+            if dist is not None:
+                raise               # (a rank that left a leg early would hang the others in the next collective)
+            legs["config4_wave"] = {"error": repr(e)}
+    if not no_legs and not os.environ.get("K16_BENCH_NO_2P26"):
+        lg = int(os.environ.get("K16_BENCH_2P26_LOG2N", "26"))
+        try:
+            legs["strong_2p%d" % lg] = strong_leg(k16, torch, dist, sharding, rank, world, dev, lg)
+        except SystemExit:
+            raise
+        except Exception as e:
+            if dist is not None:
+                raise
+            legs["strong_2p%d" % lg] = {"error": repr(e)}
+
     if rank == 0:
         total_points = float(n) * args.steps if not strong else float(1 << args.total_log2n) * args.steps
         if not strong:
             total_points *= world
         value = total_points / elapsed
         kern_s = (acc_ms / max(launches, 1)) * 1e-3
-        pts_per_launch = min(n, 1 << 24)
+        # rows one launch of the dominant kernel covers: the whole MSM up to 2^24 rows, a 2^24-row chunk above, one PIECE of one
+        # shard (k16_msm_sharded_*: 2^22 rows of host scalars per device pass) in the one-process sharded run
+        pts_per_launch = min(n, 1 << 24) if shards_obj is None else min((n + len(shard_devices) - 1) // len(shard_devices), 1 << 22)
         achieved = (pts_per_launch * ALGO_BYTES_PER_POINT) / kern_s / 1e9 if kern_s > 0 else 0.0
         traffic, traffic_src = None, None
         tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -1076,6 +1395,7 @@ def main():
             "host_scalars_leg": host_leg,
             "proof": proof,
         }
+        out.update(legs)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 n_cpu = 1 << min(args.log2n, 20)

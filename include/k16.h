@@ -120,6 +120,12 @@ int k16_dev_alloc(k16_ctx* ctx, size_t bytes, void** dptr);
 int k16_dev_free(k16_ctx* ctx, void* dptr);
 int k16_h2d(k16_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
 int k16_d2h(k16_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
+/* Page-lock a host buffer the caller owns (hipHostRegister), so that k16_h2d / k16_msm_host / k16_msm_sharded_run copy from
+ * it by DMA instead of through the runtime's staging buffer (a 2^24-row scalar array: 24 instead of 27 ms per upload, and
+ * the copy no longer occupies a host core).  The buffer must stay mapped until k16_host_unregister.  Not needed for
+ * correctness anywhere. */
+int k16_host_register(k16_ctx* ctx, void* hptr, size_t bytes);
+int k16_host_unregister(k16_ctx* ctx, void* hptr);
 
 /* ---- timing on the context's stream with HIP events ---- */
 int k16_timer_start(k16_ctx* ctx);
@@ -240,13 +246,22 @@ int         k16_msm_sharded_set_bases_device(k16_msm_shards* s, int shard, const
 int         k16_msm_sharded_run(k16_msm_shards* s, const void* h_scalars, void* h_out_xyzz, void* h_out_affine);
 /* d_scalars[r]: shard r's (hi_r - lo_r) x 32 B already on shard r's device */
 int         k16_msm_sharded_run_device(k16_msm_shards* s, const void* const* d_scalars, void* h_out_xyzz, void* h_out_affine);
+/* Rows per device pass inside a shard (same result for any value): scalars from host memory are uploaded and enqueued in
+ * pieces of host_rows (default 2^22 = 128 MB: piece i + 1 crosses PCIe while piece i is sorted and accumulated, two MSMs and
+ * one upload in flight), resident scalars in passes of device_rows (default and maximum 2^24).  0 keeps / restores the
+ * default; K16_ERR_ARG below 64 or above 2^24. */
+int         k16_msm_sharded_set_piece_rows(k16_msm_shards* s, uint64_t host_rows, uint64_t device_rows);
 /* wall time of the last run: all shards (upload + device work + per-shard combine, in parallel), the fold, the total */
 int         k16_msm_sharded_last_ms(const k16_msm_shards* s, double* shards_ms, double* fold_ms, double* total_ms);
 /* (2) One PROCESS per GPU (a launcher starts the ranks; each rank has its own context and its shard): the ranks exchange
  * their partial results with ONE ncclAllGather over xGMI and every rank folds them in rank order (RCCL has no elliptic-curve
  * reduction operator).  RCCL is dlopen'ed at the first call -- libk16.so does not link it; K16_ERR_NO_DEVICE (and
  * k16_rank_comm_load_error) when it cannot be loaded.  Rank 0 makes the 128-byte id and hands it to all ranks by whatever
- * the launcher offers (a file, MPI, a TCP store); k16_rank_comm_create is collective (ncclCommInitRank). */
+ * the launcher offers (a file, MPI, a TCP store); k16_rank_comm_create is collective (ncclCommInitRank).
+ * K16_RCCL_LIB (environment, read once per process at the first k16_rank_comm_* call) names the RCCL library file outright,
+ * for installations outside the loader's search path.  A gather is waited for at most K16_RANK_COMM_TIMEOUT_MS (read by
+ * k16_rank_comm_create; default 60 000): when a rank does not arrive in time the communicator is aborted, the call and every
+ * later one on it return K16_ERR_HIP -- a dead rank never hangs the others. */
 typedef struct k16_rank_comm k16_rank_comm;
 int         k16_rank_comm_unique_id(void* out128);
 const char* k16_rank_comm_load_error(void);
@@ -254,6 +269,12 @@ int         k16_rank_comm_create(k16_ctx* ctx, int rank, int world, const void* 
 void        k16_rank_comm_destroy(k16_rank_comm* c);
 int         k16_rank_comm_allgather_fold(k16_rank_comm* c, int group, const void* h_partial_xyzz, void* h_out_xyzz,
                                          void* h_out_affine);
+/* The same exchange split in two, for a caller that keeps the GPU busy with the next MSM meanwhile: _start enqueues the
+ * upload of this rank's partial, the ncclAllGather and the download on the communicator's stream and returns at once (up to
+ * 4 exchanges in flight, K16_ERR_ARG beyond); _finish completes the OLDEST one (bounded wait) and folds it.  Every rank must
+ * start its exchanges in the same order. */
+int         k16_rank_comm_allgather_start(k16_rank_comm* c, int group, const void* h_partial_xyzz);
+int         k16_rank_comm_allgather_finish(k16_rank_comm* c, void* h_out_xyzz, void* h_out_affine);
 
 /* combine partial MSM results from several shards/GPUs: out = sum_i parts[i] (XYZZ, host) */
 int k16_points_sum(int group, const void* h_parts_xyzz, uint64_t count, void* h_out_xyzz, void* h_out_affine);
@@ -283,6 +304,13 @@ int k16_point_op_vec(k16_ctx* ctx, int group, int op, const void* h_p1, const vo
  * exactly as groth16.cpp:296-316 does (254-bit candidates, rejection). */
 int  k16_prover_create(k16_ctx* ctx, const char* zkey_path, k16_prover** out);
 int  k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_t zkey_size, k16_prover** out);
+/* A further prover of the SAME key on the SAME device as `other` (throughput mode: several provers sharing one GPU, what
+ * FullProver builds for K16_DEVICES=0,0): it shares other's read-only device data -- point tables, H window tables,
+ * coefficients, masks, 2.7 GB at the Keyless shape -- by reference count instead of parsing, uploading and preparing the key
+ * again (0.1 s instead of 1.1 s), and owns only what a proof writes.  ctx must be a context of its own on that device.  The
+ * shared part is freed with the last prover that uses it; `other` may be destroyed first.  Same proofs as a prover made by
+ * k16_prover_create. */
+int  k16_prover_create_shared(k16_ctx* ctx, const k16_prover* other, k16_prover** out);
 void k16_prover_destroy(k16_prover* p);
 int  k16_prover_info(const k16_prover* p, uint32_t* n_vars, uint32_t* n_public, uint32_t* domain_size,
                      uint64_t* n_coefs);
@@ -321,6 +349,22 @@ int  k16_prover_prove_compact(k16_prover* p, uint64_t n_wide, const uint8_t* r_s
  * K16_ERR_FORMAT / K16_ERR_ARG / K16_ERR_BUFFER / K16_ERR_NOMEM.  prover_time_ms: wall time of the call (may be NULL). */
 int  k16_fullprover_prove_mem(const void* fullprover, const void* wtns_values, uint64_t n_values, char* out_json, size_t cap,
                               int* prover_time_ms);
+/* The compact hand-off (k16_prover_compact_buffers / k16_prover_prove_compact above) THROUGH THE POOL: the buffers belong to
+ * one prover, so the caller leases a slot first, writes the witness into that slot's buffers, and proves on it:
+ *   k16_fullprover_compact_lease     waits for a free prover like prove() does and hands out its upload buffers (same meaning
+ *                                    as k16_prover_compact_buffers) and the circuit's wire count; *lease names the slot.
+ *                                    K16_ERR_NO_DEVICE: not ready / every device retired; K16_ERR_ARG: the key's provers upload
+ *                                    plainly (below 2^16 wires) -- nothing is leased then.
+ *   k16_fullprover_prove_compact     proves the witness the leased buffers hold and gives the slot back WHATEVER the outcome
+ *                                    (results and error classes as k16_fullprover_prove_mem; a device fault rebuilds the slot).
+ *   k16_fullprover_compact_cancel    gives the slot back without proving (the witness calculator failed).
+ * A lease is for one proof and one thread; a service bounds how long it holds one (the slot serves nobody else meanwhile).
+ * Replaces the temp-file hand-off of fullprover.cpp:204-250 / prover_handler.rs:511-527 for a pooled multi-GPU service. */
+int  k16_fullprover_compact_lease(const void* fullprover, void** lease, uint8_t** narrow, uint32_t** wide_idx,
+                                  uint8_t** wide_val, uint64_t* wide_cap, uint32_t* n_vars);
+int  k16_fullprover_prove_compact(const void* fullprover, void* lease, uint64_t n_wide, char* out_json, size_t cap,
+                                  int* prover_time_ms);
+int  k16_fullprover_compact_cancel(const void* fullprover, void* lease);
 /* debugging / parity: H scalars of the last proof (domain_size x 32 B, standard form) */
 int  k16_prover_last_h(k16_prover* p, void* h_out);
 /* status of the discarded warm-up proof k16_prover_create runs (K16_OK, or the error it ended with: a prover whose device

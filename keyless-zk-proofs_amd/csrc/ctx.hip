@@ -311,6 +311,24 @@ extern "C" int k16_h2d(k16_ctx* c, void* d, const void* h, size_t bytes)
     return K16_OK;
     });
 }
+extern "C" int k16_host_register(k16_ctx* c, void* h, size_t bytes)
+{
+    return k16_guard(c, [&]() -> int {
+    if (!c || !h || !bytes) return K16_ERR_ARG;
+    K16_HIP(c, hipSetDevice(c->device));
+    K16_HIP(c, hipHostRegister(h, bytes, hipHostRegisterPortable));
+    return K16_OK;
+    });
+}
+extern "C" int k16_host_unregister(k16_ctx* c, void* h)
+{
+    return k16_guard(c, [&]() -> int {
+    if (!c || !h) return K16_ERR_ARG;
+    K16_HIP(c, hipSetDevice(c->device));
+    K16_HIP(c, hipHostUnregister(h));
+    return K16_OK;
+    });
+}
 extern "C" int k16_d2h(k16_ctx* c, void* h, const void* d, size_t bytes)
 {
     return k16_guard(c, [&]() -> int {

@@ -121,6 +121,7 @@ public:
             if (s->ctx) k16_ctx_destroy(s->ctx);
             s->prover = nullptr;
             s->ctx    = nullptr;
+            // (from the key FILE, not from a sibling's resident copy: after a device fault nothing on that device is trusted)
             ok = k16_ctx_create(s->device, &s->ctx) == K16_OK && k16_prover_create(s->ctx, zkey_path.c_str(), &s->prover) == K16_OK;
             if (ok) {
                 int sharing = 0;
@@ -208,7 +209,11 @@ FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullPro
                 delete p;
                 return;
             }
-            int rc = k16_prover_create(s.ctx, _zkeyFileName, &s.prover);
+            // a device listed before already holds the key: share its read-only part (one upload, one window-table build)
+            const k16_prover* sibling = nullptr;
+            for (auto& o : p->slots)
+                if (o.device == dev && o.prover) sibling = o.prover;
+            int rc = sibling ? k16_prover_create_shared(s.ctx, sibling, &s.prover) : k16_prover_create(s.ctx, _zkeyFileName, &s.prover);
             if (rc != K16_OK) {
                 // fullprover.cpp:91-100 : invalid_argument -> UNSUPPORTED_ZKEY_CURVE, system_error -> ZKEY_FILE_LOAD_ERROR
                 state = (rc == K16_ERR_CURVE || rc == K16_ERR_FORMAT) ? FullProverState::UNSUPPORTED_ZKEY_CURVE
@@ -272,6 +277,95 @@ extern "C" int k16_fullprover_prove_mem(const void* fullprover, const void* wtns
         return rc;
     } catch (const std::bad_alloc&) {
         return K16_ERR_NOMEM;
+    } catch (...) {
+        return K16_ERR_HIP;
+    }
+}
+
+namespace {
+struct FullProverFields { // the object's two (private) fields, in the order the header -- the reference's -- declares them
+    FullProverImpl* impl;
+    FullProverState state;
+};
+FullProverImpl* impl_of(const void* fullprover)
+{
+    static_assert(sizeof(FullProverFields) == sizeof(FullProver), "FullProver layout");
+    if (!fullprover) return nullptr;
+    FullProverFields f;
+    memcpy(&f, fullprover, sizeof f);
+    return (f.state == FullProverState::OK) ? f.impl : nullptr;
+}
+} // namespace
+
+// The compact hand-off through the pool (include/k16.h): lease a slot, hand out ITS pinned upload buffers, prove, release.
+extern "C" int k16_fullprover_compact_lease(const void* fullprover, void** lease, uint8_t** narrow, uint32_t** wide_idx,
+                                            uint8_t** wide_val, uint64_t* wide_cap, uint32_t* n_vars)
+{
+    try {
+        if (!lease || !narrow || !wide_idx || !wide_val || !wide_cap) return K16_ERR_ARG;
+        *lease = nullptr;
+        FullProverImpl* impl = impl_of(fullprover);
+        if (!impl) return K16_ERR_NO_DEVICE;
+        FullProverImpl::Slot* slot = impl->acquire();
+        if (!slot) return K16_ERR_NO_DEVICE;
+        int rc = k16_prover_compact_buffers(slot->prover, narrow, wide_idx, wide_val, wide_cap);
+        if (!rc && n_vars) rc = k16_prover_info(slot->prover, n_vars, nullptr, nullptr, nullptr);
+        if (rc) {
+            impl->release(slot);
+            return rc;
+        }
+        *lease = slot;
+        return K16_OK;
+    } catch (const std::bad_alloc&) {
+        return K16_ERR_NOMEM;
+    } catch (...) {
+        return K16_ERR_HIP;
+    }
+}
+
+static FullProverImpl::Slot* leased_slot(FullProverImpl* impl, void* lease)
+{
+    if (!impl || !lease) return nullptr;
+    for (auto& s : impl->slots)
+        if (&s == lease) return s.busy ? &s : nullptr; // (a stale or foreign pointer never reaches a prover)
+    return nullptr;
+}
+
+extern "C" int k16_fullprover_prove_compact(const void* fullprover, void* lease, uint64_t n_wide, char* out_json, size_t cap,
+                                            int* prover_time_ms)
+{
+    try {
+        if (prover_time_ms) *prover_time_ms = 0;
+        FullProverImpl*       impl = impl_of(fullprover);
+        FullProverImpl::Slot* slot = leased_slot(impl, lease);
+        if (!slot) return K16_ERR_ARG;
+        struct Release { // the slot goes back whatever happens below
+            FullProverImpl*       impl;
+            FullProverImpl::Slot* slot;
+            ~Release() { impl->release(slot); }
+        } rel{impl, slot};
+        if (!out_json) return K16_ERR_ARG;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int  rc = k16_prover_prove_compact(slot->prover, n_wide, nullptr, nullptr, out_json, cap, nullptr);
+        if (rc == K16_ERR_HIP || rc == K16_ERR_NO_DEVICE) impl->quarantine(slot);
+        if (prover_time_ms)
+            *prover_time_ms = (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return K16_ERR_NOMEM;
+    } catch (...) {
+        return K16_ERR_HIP;
+    }
+}
+
+extern "C" int k16_fullprover_compact_cancel(const void* fullprover, void* lease)
+{
+    try {
+        FullProverImpl*       impl = impl_of(fullprover);
+        FullProverImpl::Slot* slot = leased_slot(impl, lease);
+        if (!slot) return K16_ERR_ARG;
+        impl->release(slot);
+        return K16_OK;
     } catch (...) {
         return K16_ERR_HIP;
     }

@@ -20,7 +20,11 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include "ctx.h"
 
 using namespace k16;
@@ -37,6 +41,18 @@ inline size_t aff_bytes(int group) { return group == K16_G1 ? sizeof(G1Aff) : si
 inline size_t xyzz_bytes(int group) { return group == K16_G1 ? sizeof(G1Xyzz) : sizeof(G2Xyzz); }
 } // namespace
 
+// K16_FAULT_INJECT=shard_piece:<k> (libk16_testing.so only, -DK16_TESTING): the k-th piece (0-based) of every shard's pieced
+// pipeline fails before its upload -- with up to two MSMs of earlier pieces still in flight, which k16_msm_abort_all must drain.
+#ifdef K16_TESTING
+static bool shard_fault_now(uint64_t piece)
+{
+    const char* e = getenv("K16_FAULT_INJECT");
+    return e && strncmp(e, "shard_piece:", 12) == 0 && (uint64_t)atoll(e + 12) == piece;
+}
+#else
+static inline bool shard_fault_now(uint64_t) { return false; }
+#endif
+
 struct k16_msm_shards {
     int      group = K16_G1;
     uint64_t n     = 0;
@@ -52,6 +68,31 @@ struct k16_msm_shards {
     std::vector<Shard> shards;
     std::string        err;
     double             last_ms[3] = {0, 0, 0}; // upload + device work (max over shards), fold, total of the last run
+    // rows per device pass: scalars from HOST memory are uploaded in pieces of 2^22 rows (128 MB) so that piece i + 1 crosses
+    // PCIe while piece i is sorted and accumulated; resident scalars go in passes of 2^24 rows, the largest one device call
+    // takes (msm_api.hip).  k16_msm_sharded_set_piece_rows changes them (same result; tests run many small pieces).
+    uint64_t           piece_host = 1ull << 22, piece_dev = 1ull << 24;
+    // One worker thread per shard beyond the first, started once (a std::thread per shard per run is
+    // wasteful for a service that calls this at 2^22): they sleep on `cv` between runs; the calling thread takes shard 0.
+    struct Workers {
+        std::mutex                        m;
+        std::condition_variable           cv, cv_done;
+        std::vector<std::thread>          th;
+        std::function<int(Shard&)>*       job  = nullptr;
+        uint64_t                          gen  = 0;  // bumped for every job
+        unsigned                          left = 0;  // workers still running the current job
+        bool                              quit = false;
+    } w;
+    ~k16_msm_shards()
+    {
+        {
+            std::lock_guard<std::mutex> g(w.m);
+            w.quit = true;
+        }
+        w.cv.notify_all();
+        for (auto& t : w.th)
+            if (t.joinable()) t.join();
+    }
 };
 
 extern "C" int k16_msm_sharded_create(const int* devices, int n_devices, int group, uint64_t n, k16_msm_shards** out)
@@ -120,38 +161,64 @@ extern "C" k16_ctx* k16_msm_sharded_ctx(k16_msm_shards* s, int shard)
 extern "C" const char* k16_msm_sharded_last_error(const k16_msm_shards* s) { return s ? s->err.c_str() : "null handle"; }
 
 // run f(shard) on one host thread per shard (the calling thread takes shard 0) and collect the first failure
-template <class F>
-static int for_each_shard(k16_msm_shards* s, F f)
+static int run_guarded(k16_msm_shards::Shard& sh, std::function<int(k16_msm_shards::Shard&)>& f)
 {
-    std::vector<std::thread> th;
-    auto                     work = [s, &f](size_t r) {
-        try {
-            s->shards[r].rc = f(s->shards[r]);
-        } catch (const std::bad_alloc&) {
-            s->shards[r].rc = K16_ERR_NOMEM;
-        } catch (...) {
-            s->shards[r].rc = K16_ERR_HIP;
-        }
-    };
-    std::vector<size_t> inline_shards; // shards whose thread could not be started (std::system_error): run by the caller
-    th.reserve(s->shards.size());
-    for (size_t r = 1; r < s->shards.size(); r++) {
-        try {
-            th.emplace_back(work, r);
-        } catch (...) {
-            inline_shards.push_back(r);
-        }
-    }
-    try { // (an exception on the calling thread must not skip the joins: a joinable std::thread's destructor terminates)
-        s->shards[0].rc = f(s->shards[0]);
+    try {
+        return f(sh);
     } catch (const std::bad_alloc&) {
-        s->shards[0].rc = K16_ERR_NOMEM;
+        return K16_ERR_NOMEM;
     } catch (...) {
-        s->shards[0].rc = K16_ERR_HIP;
+        return K16_ERR_HIP;
     }
-    for (size_t r : inline_shards) work(r);
-    for (auto& t : th) t.join();
-    for (size_t r = 0; r < s->shards.size(); r++) {
+}
+static void shard_worker(k16_msm_shards* s, size_t r)
+{
+    auto&    W    = s->w;
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<int(k16_msm_shards::Shard&)>* job;
+        {
+            std::unique_lock<std::mutex> g(W.m);
+            W.cv.wait(g, [&] { return W.quit || W.gen != seen; });
+            if (W.quit) return;
+            seen = W.gen;
+            job  = W.job;
+        }
+        s->shards[r].rc = run_guarded(s->shards[r], *job);
+        {
+            std::lock_guard<std::mutex> g(W.m);
+            if (--W.left == 0) W.cv_done.notify_all();
+        }
+    }
+}
+static int for_each_shard(k16_msm_shards* s, std::function<int(k16_msm_shards::Shard&)> f)
+{
+    auto&        W  = s->w;
+    const size_t ns = s->shards.size();
+    // workers are started at the first use; a shard whose thread cannot be started (std::system_error) is run by the caller
+    while (W.th.size() + 1 < ns) {
+        try {
+            W.th.emplace_back(shard_worker, s, W.th.size() + 1);
+        } catch (...) {
+            break;
+        }
+    }
+    const size_t have = W.th.size(); // shards 1 .. have run on workers
+    if (have) {
+        std::lock_guard<std::mutex> g(W.m);
+        W.job  = &f;
+        W.left = (unsigned)have;
+        W.gen++;
+    }
+    if (have) W.cv.notify_all();
+    s->shards[0].rc = run_guarded(s->shards[0], f);
+    for (size_t r = have + 1; r < ns; r++) s->shards[r].rc = run_guarded(s->shards[r], f);
+    if (have) {
+        std::unique_lock<std::mutex> g(W.m);
+        W.cv_done.wait(g, [&] { return W.left == 0; });
+        W.job = nullptr;
+    }
+    for (size_t r = 0; r < ns; r++) {
         if (s->shards[r].rc) {
             s->err = "shard " + std::to_string(r) + " (device " + std::to_string(s->shards[r].device) + "): " +
                      k16_last_error(s->shards[r].ctx);
@@ -217,10 +284,10 @@ static int sharded_run(k16_msm_shards* s, const void* h_scalars, const void* con
         const void*    ds  = d_scalars ? d_scalars[r] : sh.d_scalars;
         const size_t   pb  = aff_bytes(s->group);
         // One device call takes up to 2^24 rows (msm_api.hip); scalars that arrive in HOST memory are uploaded in pieces of
-        // 2^22 rows (128 MB) so that piece i + 1 crosses PCIe while piece i is sorted and accumulated: the uploads go through
-        // the context's stream (lane 0), the MSMs alternate between lanes 1 and 2.  The pieces' partial results are folded
-        // like the shards' (one XYZZ point each).
-        const uint64_t CH = d_scalars ? (1ull << 24) : (1ull << 22);
+        // 2^22 rows (128 MB; k16_msm_shards::piece_host) so that piece i + 1 crosses PCIe while piece i is sorted and
+        // accumulated: the uploads go through the context's stream (lane 0), the MSMs alternate between lanes 1 and 2.  The
+        // pieces' partial results are folded like the shards' (one XYZZ point each).
+        const uint64_t CH = d_scalars ? s->piece_dev : s->piece_host;
         if (cnt <= CH) {
             int rc2 = K16_OK;
             if (cnt && !d_scalars) rc2 = k16_h2d(sh.ctx, sh.d_scalars, (const char*)h_scalars + sh.lo * 32, (size_t)cnt * 32);
@@ -234,6 +301,10 @@ static int sharded_run(k16_msm_shards* s, const void* h_scalars, const void* con
         int                        rc2 = K16_OK;
         auto                       next = [&]() -> int {
             const uint64_t lo = enq * CH, c = std::min<uint64_t>(CH, cnt - lo);
+            if (shard_fault_now(enq)) {
+                sh.ctx->err = "fault injected before piece " + std::to_string(enq);
+                return K16_ERR_HIP;
+            }
             if (!d_scalars) {
                 const int e = k16_h2d(sh.ctx, (char*)sh.d_scalars + lo * 32, (const char*)h_scalars + (sh.lo + lo) * 32, (size_t)c * 32);
                 if (e) return e;
@@ -282,6 +353,16 @@ extern "C" int k16_msm_sharded_run_device(k16_msm_shards* s, const void* const* 
         return sharded_run(s, nullptr, d_scalars, h_out_xyzz, h_out_affine);
     });
 }
+extern "C" int k16_msm_sharded_set_piece_rows(k16_msm_shards* s, uint64_t host_rows, uint64_t device_rows)
+{
+    if (!s) return K16_ERR_ARG;
+    // (a piece is one device pass: at most 2^24 rows; below 64 rows the pipeline is all overhead, refuse obvious mistakes)
+    if ((host_rows && (host_rows < 64 || host_rows > (1ull << 24))) || (device_rows && (device_rows < 64 || device_rows > (1ull << 24))))
+        return K16_ERR_ARG;
+    s->piece_host = host_rows ? host_rows : (1ull << 22);
+    s->piece_dev  = device_rows ? device_rows : (1ull << 24);
+    return K16_OK;
+}
 extern "C" int k16_msm_sharded_last_ms(const k16_msm_shards* s, double* shards_ms, double* fold_ms, double* total_ms)
 {
     if (!s) return K16_ERR_ARG;
@@ -304,6 +385,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclId*)                                                         = nullptr;
     int (*CommInitRank)(NcclComm*, int, NcclId, int)                                    = nullptr;
     int (*CommDestroy)(NcclComm)                                                        = nullptr;
+    int (*CommAbort)(NcclComm)                                                          = nullptr; // optional
     int (*AllGather)(const void*, void*, size_t, int /*ncclDataType_t*/, NcclComm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int)                                                  = nullptr;
     std::string err;
@@ -313,18 +395,33 @@ Rccl* rccl()
     static Rccl       r;
     static std::once_flag once;
     std::call_once(once, []() {
+        // K16_RCCL_LIB names the library file outright (an installation outside the loader's search path; the test double of
+        // tests/cpp/fake_rccl.cpp): then nothing else is tried.  Read once per process, here.
+        const char* forced  = getenv("K16_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* nm : names) {
-            r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        std::string why;
+        if (forced && *forced) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) {
+                const char* e = dlerror(); // (dlerror() clears the message it returns: call it ONCE -- ADVICE r5)
+                why           = e ? e : "not found";
+            }
+        } else {
+            for (const char* nm : names) {
+                r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+                const char* e = dlerror();
+                if (why.empty()) why = e ? e : "not found";
+            }
         }
         if (!r.lib) {
-            r.err = std::string("dlopen librccl: ") + (dlerror() ? dlerror() : "not found");
+            r.err = "dlopen librccl: " + why;
             return;
         }
         r.GetUniqueId    = (int (*)(NcclId*))dlsym(r.lib, "ncclGetUniqueId");
         r.CommInitRank   = (int (*)(NcclComm*, int, NcclId, int))dlsym(r.lib, "ncclCommInitRank");
         r.CommDestroy    = (int (*)(NcclComm))dlsym(r.lib, "ncclCommDestroy");
+        r.CommAbort      = (int (*)(NcclComm))dlsym(r.lib, "ncclCommAbort");
         r.AllGather      = (int (*)(const void*, void*, size_t, int, NcclComm, hipStream_t))dlsym(r.lib, "ncclAllGather");
         r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
         if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) {
@@ -342,9 +439,22 @@ struct k16_rank_comm {
     NcclComm    comm = nullptr;
     int         rank = 0, world = 1;
     hipStream_t stream = nullptr;
-    void*       d_send = nullptr; // 256 B
-    void*       d_recv = nullptr; // world x 256 B
-    void*       h_pin  = nullptr; // (1 + world) x 256 B, page-locked
+    // A ring of exchanges in flight (k16_rank_comm_allgather_start / _finish, FIFO): slot k = 256 B to send, world x 256 B
+    // received (device), the same page-locked on the host, an event behind the download.
+    static constexpr int SLOTS = 4;
+    struct Slot {
+        void*      d_send = nullptr;
+        void*      d_recv = nullptr;
+        void*      h_pin  = nullptr; // (1 + world) x 256 B
+        hipEvent_t done   = nullptr;
+        int        group  = K16_G1;
+    } slot[SLOTS];
+    unsigned    head = 0, tail = 0; // tail - head exchanges in flight
+    // A rank that never arrives (it died, or its launcher did) would leave the others inside the collective for ever: the
+    // gather is waited for at most this long (K16_RANK_COMM_TIMEOUT_MS, read when the communicator is created; default 60 s),
+    // then the communicator is aborted (ncclCommAbort) and every later call fails at once with K16_ERR_HIP.
+    int         timeout_ms = 60000;
+    bool        dead       = false;
     std::string err;
 };
 
@@ -380,6 +490,8 @@ extern "C" int k16_rank_comm_create(k16_ctx* ctx, int rank, int world, const voi
         c->ctx   = ctx;
         c->rank  = rank;
         c->world = world;
+        if (const char* t = getenv("K16_RANK_COMM_TIMEOUT_MS"))
+            if (atoi(t) > 0) c->timeout_ms = atoi(t);
         NcclId id;
         memcpy(&id, unique_id128, sizeof id);
         const int e = R->CommInitRank(&c->comm, world, id, rank);
@@ -389,9 +501,12 @@ extern "C" int k16_rank_comm_create(k16_ctx* ctx, int rank, int world, const voi
             return K16_ERR_HIP;
         }
         K16_HIP(ctx, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        K16_HIP(ctx, hipMalloc(&c->d_send, 256));
-        K16_HIP(ctx, hipMalloc(&c->d_recv, (size_t)world * 256));
-        K16_HIP(ctx, hipHostMalloc(&c->h_pin, (size_t)(1 + world) * 256, hipHostMallocDefault));
+        for (auto& sl : c->slot) {
+            K16_HIP(ctx, hipMalloc(&sl.d_send, 256));
+            K16_HIP(ctx, hipMalloc(&sl.d_recv, (size_t)world * 256));
+            K16_HIP(ctx, hipHostMalloc(&sl.h_pin, (size_t)(1 + world) * 256, hipHostMallocDefault));
+            K16_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        }
         return K16_OK;
     });
     if (rc) {
@@ -406,35 +521,96 @@ extern "C" void k16_rank_comm_destroy(k16_rank_comm* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->ctx->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->comm) (void)rccl()->CommDestroy(c->comm);
-    if (c->d_send) (void)hipFree(c->d_send);
-    if (c->d_recv) (void)hipFree(c->d_recv);
-    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->stream && !c->dead) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && !c->dead) (void)rccl()->CommDestroy(c->comm); // (an aborted communicator is already gone)
+    for (auto& sl : c->slot) {
+        if (sl.d_send) (void)hipFree(sl.d_send);
+        if (sl.d_recv) (void)hipFree(sl.d_recv);
+        if (sl.h_pin) (void)hipHostFree(sl.h_pin);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+static int rank_comm_fail(k16_rank_comm* c, const std::string& why)
+{
+    c->dead     = true; // (the state of the other ranks is unknown: no further collective on this communicator)
+    c->ctx->err = why;
+    Rccl* R     = rccl();
+    if (R->CommAbort && c->comm) (void)R->CommAbort(c->comm);
+    c->head = c->tail = 0;
+    return K16_ERR_HIP;
+}
+
+// Enqueue this rank's part of one exchange (upload of the partial, ncclAllGather, download of all partials) on the
+// communicator's stream and return: nothing waits.  Up to SLOTS exchanges may be in flight; _finish completes the oldest.
+extern "C" int k16_rank_comm_allgather_start(k16_rank_comm* c, int group, const void* h_partial_xyzz)
+{
+    k16_ctx* ctx = c ? c->ctx : nullptr;
+    return k16_guard(ctx, [&]() -> int {
+        if (!c || !h_partial_xyzz || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
+        if (c->dead) {
+            ctx->err = "rank communicator was aborted (a rank did not arrive in time)";
+            return K16_ERR_HIP;
+        }
+        if (c->tail - c->head >= (unsigned)k16_rank_comm::SLOTS) {
+            ctx->err = "k16_rank_comm_allgather_start: too many exchanges in flight (finish one first)";
+            return K16_ERR_ARG;
+        }
+        Rccl*        R  = rccl();
+        const size_t xb = xyzz_bytes(group);
+        auto&        sl = c->slot[c->tail % k16_rank_comm::SLOTS];
+        K16_HIP(ctx, hipSetDevice(ctx->device));
+        memcpy(sl.h_pin, h_partial_xyzz, xb);
+        sl.group = group;
+        K16_HIP(ctx, hipMemcpyAsync(sl.d_send, sl.h_pin, xb, hipMemcpyHostToDevice, c->stream));
+        const int e = R->AllGather(sl.d_send, sl.d_recv, xb, /*ncclUint8*/ 1, c->comm, c->stream);
+        if (e != 0) return rank_comm_fail(c, std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(e) : "error"));
+        K16_HIP(ctx, hipMemcpyAsync((char*)sl.h_pin + 256, sl.d_recv, (size_t)c->world * xb, hipMemcpyDeviceToHost, c->stream));
+        K16_HIP(ctx, hipEventRecord(sl.done, c->stream));
+        c->tail++;
+        return K16_OK;
+    });
+}
+
+// Complete the OLDEST exchange in flight: bounded wait (k16_rank_comm::timeout_ms; polls, never blocks inside the runtime),
+// then the EC-add fold of the world's partials in rank order -- the same on every rank.
+extern "C" int k16_rank_comm_allgather_finish(k16_rank_comm* c, void* h_out_xyzz, void* h_out_affine)
+{
+    k16_ctx* ctx = c ? c->ctx : nullptr;
+    return k16_guard(ctx, [&]() -> int {
+        if (!c) return K16_ERR_ARG;
+        if (c->dead) {
+            ctx->err = "rank communicator was aborted (a rank did not arrive in time)";
+            return K16_ERR_HIP;
+        }
+        if (c->tail == c->head) {
+            ctx->err = "k16_rank_comm_allgather_finish: no exchange in flight";
+            return K16_ERR_ARG;
+        }
+        auto& sl = c->slot[c->head % k16_rank_comm::SLOTS];
+        K16_HIP(ctx, hipSetDevice(ctx->device));
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(c->timeout_ms);
+        for (unsigned spins = 0;; spins++) {
+            const hipError_t q = hipEventQuery(sl.done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) K16_HIP(ctx, q);
+            if (std::chrono::steady_clock::now() > t_end)
+                return rank_comm_fail(c, "ncclAllGather: not all " + std::to_string(c->world) + " ranks arrived within " +
+                                             std::to_string(c->timeout_ms) + " ms (communicator aborted)");
+            if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50)); // (the usual case is over in ~20 us)
+        }
+        c->head++;
+        return k16_points_sum(sl.group, (char*)sl.h_pin + 256, (uint64_t)c->world, h_out_xyzz, h_out_affine);
+    });
 }
 
 // every rank passes ITS shard's partial result (XYZZ, host) and receives the MSM's result: gather + EC-add fold in rank order
 extern "C" int k16_rank_comm_allgather_fold(k16_rank_comm* c, int group, const void* h_partial_xyzz, void* h_out_xyzz,
                                             void* h_out_affine)
 {
-    k16_ctx* ctx = c ? c->ctx : nullptr;
-    return k16_guard(ctx, [&]() -> int {
-        if (!c || !h_partial_xyzz || (group != K16_G1 && group != K16_G2)) return K16_ERR_ARG;
-        Rccl*        R  = rccl();
-        const size_t xb = xyzz_bytes(group);
-        K16_HIP(ctx, hipSetDevice(ctx->device));
-        memcpy(c->h_pin, h_partial_xyzz, xb);
-        K16_HIP(ctx, hipMemcpyAsync(c->d_send, c->h_pin, xb, hipMemcpyHostToDevice, c->stream));
-        const int e = R->AllGather(c->d_send, c->d_recv, xb, /*ncclUint8*/ 1, c->comm, c->stream);
-        if (e != 0) {
-            ctx->err = std::string("ncclAllGather: ") + (R->GetErrorString ? R->GetErrorString(e) : "error");
-            return K16_ERR_HIP;
-        }
-        char* back = (char*)c->h_pin + 256;
-        K16_HIP(ctx, hipMemcpyAsync(back, c->d_recv, (size_t)c->world * xb, hipMemcpyDeviceToHost, c->stream));
-        K16_HIP(ctx, hipStreamSynchronize(c->stream));
-        return k16_points_sum(group, back, (uint64_t)c->world, h_out_xyzz, h_out_affine);
-    });
+    if (c && c->tail != c->head) return K16_ERR_ARG; // (mixing it with exchanges in flight would return THEIR result)
+    const int rc = k16_rank_comm_allgather_start(c, group, h_partial_xyzz);
+    return rc ? rc : k16_rank_comm_allgather_finish(c, h_out_xyzz, h_out_affine);
 }

@@ -24,6 +24,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <sched.h>
 #include <string>
@@ -380,8 +381,24 @@ __attribute__((noinline)) G2Xyzz h_mul(const G2Xyzz& a, const uint8_t* k) { retu
 
 } // namespace
 
+// The device-resident READ-ONLY part of a prover -- point tables in the kernels' row layout, the H window tables, the regrouped
+// coefficients, the zero-row masks, the coset-shift table: 2.7 GB at the Keyless shape -- owned by reference count, so that
+// several provers of one key on ONE device (FullProver's K16_DEVICES=0,0: throughput mode) upload and prepare it once
+// (k16_prover_create_shared).  Freed on its device when the last prover that uses it goes.
+struct ProverKeyOwner {
+    int                device = 0;
+    std::vector<void*> bufs;
+    ~ProverKeyOwner()
+    {
+        (void)hipSetDevice(device);
+        for (void* b : bufs)
+            if (b) (void)hipFree(b);
+    }
+};
+
 struct k16_prover {
     k16_ctx* ctx = nullptr;
+    std::shared_ptr<ProverKeyOwner> key; // set once the key part is complete; until then prover_free frees the buffers itself
     uint32_t n_vars = 0, n_public = 0, domain_size = 0, logN = 0;
     uint64_t n_coefs = 0;
     G1Aff    alpha1, beta1, delta1;
@@ -541,20 +558,26 @@ static uint64_t count_wide_host(k16_ctx* ctx, const void* h_wtns, uint64_t n)
     return c;
 }
 
+static std::vector<void*> prover_key_buffers(const k16_prover* p)
+{
+    return {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_Htab, p->d_B2, p->d_slices, p->d_longs, p->d_rowof, p->d_wire, p->d_coef,
+            p->d_shift9, p->d_zmask[0], p->d_zmask[1], p->d_zmask[2], p->d_zmask[3], p->d_skip_ac, p->d_skip_b};
+}
+
 static void prover_free(k16_prover* p)
 {
     if (!p) return;
-    void* bufs[] = {p->d_A, p->d_B1, p->d_C, p->d_H, p->d_Htab, p->d_B2, p->d_slices, p->d_longs, p->d_rowof, p->d_wire, p->d_coef,
-                    p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t[0], p->d_t[1], p->d_t[2], p->d_shift9, p->d_n16};
-    for (void* b : bufs)
+    void* own[] = {p->d_wtns, p->d_a, p->d_b, p->d_c, p->d_t[0], p->d_t[1], p->d_t[2], p->d_n16}; // per-proof buffers
+    for (void* b : own)
         if (b) (void)hipFree(b);
+    if (!p->key) { // a half-built prover: the key part is still its own
+        for (void* b : prover_key_buffers(p))
+            if (b) (void)hipFree(b);
+    }
+    p->key.reset(); // (the last prover of a shared key frees it here)
     if (p->st2) (void)hipStreamDestroy(p->st2);
     if (p->ev_w) (void)hipEventDestroy(p->ev_w);
     if (p->ev_h) (void)hipEventDestroy(p->ev_h);
-    for (void* m : p->d_zmask)
-        if (m) (void)hipFree(m);
-    if (p->d_skip_ac) (void)hipFree(p->d_skip_ac);
-    if (p->d_skip_b) (void)hipFree(p->d_skip_b);
     if (p->cls) k16_scalar_classes_destroy(p->cls);
     delete p->packer;
     delete p;
@@ -569,6 +592,8 @@ static void prover_free(k16_prover* p)
             return K16_ERR_HIP;                                                   \
         }                                                                         \
     } while (0)
+
+static int prover_finish_create(k16_prover* p, k16_prover** out);
 
 extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_t zkey_size, k16_prover** out)
 {
@@ -837,6 +862,21 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
             }
         }
     }
+    // the key part is complete: from here on it is owned by reference count (k16_prover_create_shared hands it to siblings)
+    {
+        auto owner    = std::make_shared<ProverKeyOwner>();
+        owner->device = ctx->device;
+        owner->bufs   = prover_key_buffers(p);
+        p->key        = std::move(owner);
+    }
+    return prover_finish_create(p, out);
+    });
+}
+
+// what k16_prover_create_mem and k16_prover_create_shared have in common once the key part stands: the discarded warm-up proof
+static int prover_finish_create(k16_prover* p, k16_prover** out)
+{
+    k16_ctx* ctx = p->ctx;
 #ifdef K16_TESTING
     const bool fault_env = getenv("K16_FAULT_INJECT") != nullptr;
 #else
@@ -855,6 +895,76 @@ extern "C" int k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_
     }
     *out = p;
     return K16_OK;
+}
+
+// A further prover of the SAME key on the SAME device (include/k16.h): shares `other`'s read-only device data by reference
+// count and builds only what a proof writes -- witness / polynomial buffers, MSM lanes (the context's), chain stream, upload
+// buffers, scalar-class workspace -- plus this context's root table (made on the device in a few ms, not uploaded).
+extern "C" int k16_prover_create_shared(k16_ctx* ctx, const k16_prover* other, k16_prover** out)
+{
+    return k16_guard(ctx, [&]() -> int {
+    if (!ctx || !other || !out) return K16_ERR_ARG;
+    *out = nullptr;
+    if (!other->key || other->ctx->device != ctx->device) {
+        ctx->err = "k16_prover_create_shared: the other prover lives on another device";
+        return K16_ERR_ARG;
+    }
+    if (ctx == other->ctx) {
+        ctx->err = "k16_prover_create_shared: a prover needs a context of its own (MSM lanes, staging slots)";
+        return K16_ERR_ARG;
+    }
+    k16_prover* p = new k16_prover();
+    struct FreeOnUnwind {
+        k16_prover* p;
+        int         base = std::uncaught_exceptions();
+        ~FreeOnUnwind()
+        {
+            if (std::uncaught_exceptions() > base) prover_free(p);
+        }
+    } free_on_unwind{p};
+    *p          = *other;      // header values, key pointers, plan sizes, sort choices, the key's owner (+1)
+    p->ctx      = ctx;
+    p->d_wtns = p->d_a = p->d_b = p->d_c = nullptr; // everything a proof writes is this prover's own
+    p->d_t[0] = p->d_t[1] = p->d_t[2] = nullptr;
+    p->d_n16  = nullptr;
+    p->ntt    = nullptr;
+    p->st2    = nullptr;
+    p->ev_w = p->ev_h = nullptr;
+    p->packer = nullptr;
+    p->cls    = nullptr;
+    p->last_h.clear();
+    p->warmup_rc = 0;
+    const size_t   nv = p->n_vars;
+    const uint32_t N  = p->domain_size;
+    K16_HIP_P(ctx, hipSetDevice(ctx->device), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_wtns, nv * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_n16, nv * 2 + 64), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_a, (size_t)N * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_b, (size_t)N * 32), p);
+    K16_HIP_P(ctx, hipMalloc((void**)&p->d_c, (size_t)N * 32), p);
+    for (int k = 0; k < 3; k++) K16_HIP_P(ctx, hipMalloc((void**)&p->d_t[k], (size_t)N * 32), p);
+    int rc = k16_ntt_get_table(ctx, 2ull * N, &p->ntt);
+    if (rc) {
+        prover_free(p);
+        return rc;
+    }
+    K16_HIP_P(ctx, hipStreamSynchronize(ctx->stream), p);
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (ctx->tune.no_stream_priority) greatest = 0;
+        K16_HIP_P(ctx, hipStreamCreateWithPriority(&p->st2, hipStreamNonBlocking, greatest), p);
+    }
+    K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_w, hipEventDisableTiming), p);
+    K16_HIP_P(ctx, hipEventCreateWithFlags(&p->ev_h, hipEventDisableTiming), p);
+    p->packer = packer_create(ctx, p->n_vars);
+    if (other->cls) { // (K16_CLASSES=1: the lists are per-proof workspace; the masks they read are the key's)
+        if ((rc = k16_scalar_classes_create(ctx, p->n_vars, p->n_sets, &p->cls))) {
+            prover_free(p);
+            return rc;
+        }
+    }
+    return prover_finish_create(p, out);
     });
 }
 
@@ -955,6 +1065,7 @@ static int prove_guarded(k16_prover* p, const void* h_wtns, uint64_t n_vars, int
         }
         (void)k16_msm_abort_all(ctx); // overwrites ctx->err only when an MSM in flight failed itself
         if (p->st2) (void)hipStreamSynchronize(p->st2);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); // (the witness expansion: it writes the packer's bad-entry flag)
         ctx->forced_c         = 0;
         ctx->parallel_combine = false;
         try {
@@ -1051,14 +1162,19 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
     };
     K16_HIP(ctx, hipEventRecord(ctx->ev_a, st));
     int64_t n_wide = -1; // wide (>= 256) witness values, counted on the host: the classification then needs no round trip
+    // The bad-entry flag belongs to THIS proof's list kernel: cleared before every proof (a failed compact call must not fail
+    // the next, plainly uploaded witness -- ADVICE r5) and looked at only when the packed branch ran.  prove_guarded drains
+    // the context's stream after a failure, so no kernel of an earlier proof can still write it.
+    bool packed_upload = false;
+    if (p->packer) *p->packer->h_bad = 0;
     if (p->packer && (prepacked >= 0 || p->packer->pack(h_wtns))) {
+        packed_upload    = true;
         WitnessPacker* w = p->packer;
         n_wide           = prepacked >= 0 ? prepacked : (int64_t)w->wide_total();
         WideLists      L;
         L.n_lists = w->n_threads;
         L.n_vars  = p->n_vars;
         L.bad     = w->d_bad;
-        *w->h_bad = 0;
         uint32_t most = 0;
         for (unsigned t = 0; t < w->n_threads; t++) {
             L.idx[t]   = w->d_idx + (size_t)t * w->cap;
@@ -1328,7 +1444,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
     K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
-    if (p->packer && *p->packer->h_bad) { // (every MSM of this proof has been consumed: nothing is left behind)
+    if (packed_upload && *p->packer->h_bad) { // (every MSM of this proof has been consumed: nothing is left behind)
         ctx->err = (*p->packer->h_bad & 1u) ? "compact witness: wire number out of range in the wide-value list"
                                             : "compact witness: a listed wire must have a zero byte in the narrow array";
         return K16_ERR_FORMAT;

@@ -33,18 +33,18 @@ ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -
 # every symbol include/k16.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "k16_runtime_hw_queues", "k16_device_count", "k16_host_threads", "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
-    "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h",
+    "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h", "k16_host_register", "k16_host_unregister",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
     "k16_msm_zero_row_mask", "k16_msm_set_zero_row_mask", "k16_msm_sort_from_lane", "k16_scalar_classes_create", "k16_scalar_classes_destroy", "k16_scalar_classes_build", "k16_scalar_classes_counts", "k16_msm_enqueue_classified",
     "k16_ntt", "k16_ntt_host", "k16_synth_points", "k16_synth_points_scalars", "k16_field_op_vec", "k16_point_op_vec",
-    "k16_prover_create", "k16_prover_create_mem", "k16_prover_destroy", "k16_prover_info",
-    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_compact_buffers", "k16_prover_prove_compact", "k16_fullprover_prove_mem", "k16_prover_last_h", "k16_prover_warmup_status",
+    "k16_prover_create", "k16_prover_create_mem", "k16_prover_create_shared", "k16_prover_destroy", "k16_prover_info",
+    "k16_prover_prove_file", "k16_prover_prove_file_timed", "k16_prover_prove_mem", "k16_prover_compact_buffers", "k16_prover_prove_compact", "k16_fullprover_prove_mem", "k16_fullprover_compact_lease", "k16_fullprover_prove_compact", "k16_fullprover_compact_cancel", "k16_prover_last_h", "k16_prover_warmup_status",
     "k16_vk_create", "k16_vk_destroy", "k16_verify_batch", "k16_verify_coop_gt", "k16_pairing_vec",
     "k16_msm_sharded_create", "k16_msm_sharded_destroy", "k16_msm_sharded_count", "k16_msm_sharded_range", "k16_msm_sharded_ctx",
     "k16_msm_sharded_last_error", "k16_msm_sharded_set_bases", "k16_msm_sharded_set_bases_device", "k16_msm_sharded_run",
-    "k16_msm_sharded_run_device", "k16_msm_sharded_last_ms",
-    "k16_rank_comm_unique_id", "k16_rank_comm_load_error", "k16_rank_comm_create", "k16_rank_comm_destroy", "k16_rank_comm_allgather_fold",
+    "k16_msm_sharded_run_device", "k16_msm_sharded_set_piece_rows", "k16_msm_sharded_last_ms",
+    "k16_rank_comm_unique_id", "k16_rank_comm_load_error", "k16_rank_comm_create", "k16_rank_comm_destroy", "k16_rank_comm_allgather_fold", "k16_rank_comm_allgather_start", "k16_rank_comm_allgather_finish",
 ]
 
 _lib = None
@@ -77,6 +77,8 @@ def load():
     L.k16_dev_free.argtypes = [vp, vp]
     L.k16_h2d.argtypes = [vp, vp, vp, sz]
     L.k16_d2h.argtypes = [vp, vp, vp, sz]
+    L.k16_host_register.argtypes = [vp, vp, sz]
+    L.k16_host_unregister.argtypes = [vp, vp]
     L.k16_timer_start.argtypes = [vp]
     L.k16_timer_stop.argtypes = [vp, C.POINTER(C.c_float)]
     L.k16_kernel_stats_enable.argtypes = [vp, i32]
@@ -115,6 +117,7 @@ def load():
     L.k16_point_op_vec.argtypes = [vp, i32, i32, vp, vp, vp, u64]
     L.k16_prover_create.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     L.k16_prover_create_mem.argtypes = [vp, vp, sz, C.POINTER(vp)]
+    L.k16_prover_create_shared.argtypes = [vp, vp, C.POINTER(vp)]
     L.k16_prover_destroy.argtypes = [vp]
     L.k16_prover_destroy.restype = None
     L.k16_prover_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
@@ -124,6 +127,10 @@ def load():
     L.k16_prover_compact_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
     L.k16_prover_prove_compact.argtypes = [vp, u64, vp, vp, C.c_char_p, sz, C.POINTER(C.c_float)]
     L.k16_prover_last_h.argtypes = [vp, vp]
+    L.k16_fullprover_prove_mem.argtypes = [vp, vp, u64, C.c_char_p, sz, C.POINTER(i32)]
+    L.k16_fullprover_compact_lease.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(u32)]
+    L.k16_fullprover_prove_compact.argtypes = [vp, vp, u64, C.c_char_p, sz, C.POINTER(i32)]
+    L.k16_fullprover_compact_cancel.argtypes = [vp, vp]
     L.k16_prover_warmup_status.argtypes = [vp]
     L.k16_vk_create.argtypes = [vp, vp, vp, vp, vp, vp, u32, C.POINTER(vp)]
     L.k16_vk_destroy.argtypes = [vp]
@@ -145,6 +152,7 @@ def load():
     L.k16_msm_sharded_run.argtypes = [vp, vp, vp, vp]
     L.k16_msm_sharded_run_device.argtypes = [vp, C.POINTER(vp), vp, vp]
     L.k16_msm_sharded_last_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.k16_msm_sharded_set_piece_rows.argtypes = [vp, u64, u64]
     L.k16_rank_comm_unique_id.argtypes = [vp]
     L.k16_rank_comm_load_error.argtypes = []
     L.k16_rank_comm_load_error.restype = C.c_char_p
@@ -152,6 +160,8 @@ def load():
     L.k16_rank_comm_destroy.argtypes = [vp]
     L.k16_rank_comm_destroy.restype = None
     L.k16_rank_comm_allgather_fold.argtypes = [vp, i32, vp, vp, vp]
+    L.k16_rank_comm_allgather_start.argtypes = [vp, i32, vp]
+    L.k16_rank_comm_allgather_finish.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -406,10 +416,14 @@ def points_sum(group, parts):
 class Prover:
     """Mirror of the reference's FullProver(zkey).prove(wtns) (fullprover.hpp:52-64) over the C ABI."""
 
-    def __init__(self, ctx, zkey_path):
+    def __init__(self, ctx, zkey_path, share_key_of=None):
+        """share_key_of: another Prover of the same key on the same device -- k16_prover_create_shared (one resident key)"""
         self.ctx = ctx
         h = C.c_void_p()
-        rc = ctx.L.k16_prover_create(ctx.h, zkey_path.encode(), C.byref(h))
+        if share_key_of is not None:
+            rc = ctx.L.k16_prover_create_shared(ctx.h, share_key_of.h, C.byref(h))
+        else:
+            rc = ctx.L.k16_prover_create(ctx.h, zkey_path.encode(), C.byref(h))
         if rc:
             raise K16Error(rc, (ctx.L.k16_last_error(ctx.h) or b"").decode())
         self.h = h
@@ -592,6 +606,10 @@ class ShardedMsm:
         self._chk(self.L.k16_msm_sharded_run_device(self.h, arr, _p(x), _p(a)))
         return x.tobytes(), a.tobytes()
 
+    def set_piece_rows(self, host_rows=0, device_rows=0):
+        """rows per device pass inside a shard (include/k16.h; 0 = default 2^22 / 2^24); same result for any value"""
+        self._chk(self.L.k16_msm_sharded_set_piece_rows(self.h, host_rows, device_rows))
+
     def last_ms(self):
         a, b, c = C.c_double(), C.c_double(), C.c_double()
         self.L.k16_msm_sharded_last_ms(self.h, C.byref(a), C.byref(b), C.byref(c))
@@ -629,6 +647,19 @@ class RankComm:
         x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
         a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
         self.ctx._chk(self.L.k16_rank_comm_allgather_fold(self.h, group, _p(part), _p(x), _p(a)))
+        return x.tobytes(), a.tobytes()
+
+    def allgather_start(self, group, partial_xyzz):
+        """enqueue one exchange and return (include/k16.h: up to 4 in flight, completed in order by allgather_finish)"""
+        part = np.frombuffer(partial_xyzz, dtype=np.uint8).copy()
+        self.ctx._chk(self.L.k16_rank_comm_allgather_start(self.h, group, _p(part)))
+        self._groups = getattr(self, "_groups", []) + [group]
+
+    def allgather_finish(self):
+        group = self._groups.pop(0)
+        x = np.zeros(XYZZ_BYTES[group], dtype=np.uint8)
+        a = np.zeros(AFF_BYTES[group], dtype=np.uint8)
+        self.ctx._chk(self.L.k16_rank_comm_allgather_finish(self.h, _p(x), _p(a)))
         return x.tobytes(), a.tobytes()
 
     def close(self):

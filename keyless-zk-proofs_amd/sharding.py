@@ -89,15 +89,48 @@ class RankExchange:
     store here: it carries rank 0's communicator id to the other ranks; the collective itself is the library's."""
 
     def __init__(self, dist, ctx):
+        """Collective, and it fails on ALL ranks or on none: rank 0's failure to make the id travels in the
+        broadcast itself, and the outcome of ncclCommInitRank is agreed on with an all_gather before anybody returns -- a rank
+        that raised on its own would leave the others inside the next collective."""
         rank, world = dist.get_rank(), dist.get_world_size()
-        box = [k16.RankComm.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box = [("id", k16.RankComm.unique_id())]
+            except Exception as e:               # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+                box = [("error", repr(e))]
         dist.broadcast_object_list(box, src=0)
-        self.comm = k16.RankComm(ctx, rank, world, box[0])
+        kind, payload = box[0]
+        if kind != "id":
+            raise RuntimeError("rank 0 could not create the communicator id: %s" % payload)
+        self.comm, err = None, None
+        try:
+            self.comm = k16.RankComm(ctx, rank, world, payload)
+        except Exception as e:                   # noqa: BLE001
+            err = repr(e)
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        if any(errs):
+            if self.comm is not None:
+                self.comm.close()
+                self.comm = None
+            raise RuntimeError("k16_rank_comm_create failed on rank(s) %s: %s"
+                               % ([r for r, e in enumerate(errs) if e], next(e for e in errs if e)))
         self.world = world
 
     def exchange_and_fold(self, group, partial_xyzz):
         """all ranks' partial results gathered with ONE ncclAllGather and folded in rank order: (xyzz_bytes, affine_bytes)"""
         return self.comm.allgather_fold(group, partial_xyzz)
 
+    def start(self, group, partial_xyzz):
+        """enqueue one exchange (k16_rank_comm_allgather_start; up to 4 in flight) -- nothing waits"""
+        self.comm.allgather_start(group, partial_xyzz)
+
+    def finish(self):
+        """complete the oldest exchange in flight and fold it: (xyzz_bytes, affine_bytes)"""
+        return self.comm.allgather_finish()
+
     def close(self):
-        self.comm.close()
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None

@@ -85,6 +85,10 @@ int main(int argc, char** argv)
     printf("state=%d\n", (int)pk.state);
     const int threads = argc > 4 ? atoi(argv[4]) : 1;
     const bool mem = getenv("K16_HARNESS_MEM") != nullptr;
+    // K16_HARNESS_MEM=compact: the pool's compact hand-off (k16_fullprover_compact_lease / _prove_compact): lease a slot, write
+    // the witness in the upload form into ITS pinned buffers (what a witness calculator would do while it computes the
+    // wires), prove on it.  `us=` is the prove call alone (the hand-off's point is that the call no longer scans 43 MB).
+    const bool compact = mem && strcmp(getenv("K16_HARNESS_MEM"), "compact") == 0;
     std::vector<std::vector<unsigned char>> values(wtns.size());
     if (mem)
         for (size_t i = 0; i < wtns.size(); i++)
@@ -96,8 +100,44 @@ int main(int argc, char** argv)
         }
         char js[4096];
         int  ms = 0;
-        const int rc = values[wi].empty() ? K16_ERR_FORMAT
-                                          : k16_fullprover_prove_mem(&p, values[wi].data(), values[wi].size() / 32, js, sizeof js, &ms);
+        int  rc = K16_ERR_FORMAT;
+        if (compact && !values[wi].empty()) {
+            void*     lease = nullptr;
+            uint8_t * narrow = nullptr, *val = nullptr;
+            uint32_t* idx = nullptr;
+            uint64_t  cap = 0;
+            uint32_t  nv = 0;
+            rc = k16_fullprover_compact_lease(&p, &lease, &narrow, &idx, &val, &cap, &nv);
+            if (rc == K16_OK) {
+                const unsigned char* w = values[wi].data();
+                uint64_t             n_wide = 0;
+                bool                 fits = values[wi].size() / 32 >= nv;
+                for (uint32_t i = 0; fits && i < nv; i++) {
+                    bool wide = false;
+                    for (int b = 1; b < 32; b++) wide |= w[(size_t)i * 32 + b] != 0;
+                    narrow[i] = wide ? 0 : w[(size_t)i * 32];
+                    if (wide) {
+                        if (n_wide >= cap) {
+                            fits = false;
+                            break;
+                        }
+                        idx[n_wide] = i;
+                        memcpy(val + n_wide * 32, w + (size_t)i * 32, 32);
+                        n_wide++;
+                    }
+                }
+                if (!fits) { // more wide values than the list holds: give the slot back, take the full-witness entry point
+                    (void)k16_fullprover_compact_cancel(&p, lease);
+                    rc = k16_fullprover_prove_mem(&p, w, values[wi].size() / 32, js, sizeof js, &ms);
+                } else {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    rc            = k16_fullprover_prove_compact(&p, lease, n_wide, js, sizeof js, &ms);
+                    ms = (int)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+                }
+            }
+        } else if (!values[wi].empty()) {
+            rc = k16_fullprover_prove_mem(&p, values[wi].data(), values[wi].size() / 32, js, sizeof js, &ms);
+        }
         if (rc < 0) return MemResponse{1, rc == K16_ERR_NO_DEVICE || rc == K16_ERR_HIP || rc == K16_ERR_NOMEM ? 1 : 2, ms, ""};
         return MemResponse{0, 0, ms, js};
     };

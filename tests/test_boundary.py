@@ -71,9 +71,29 @@ def test_production_library_has_no_result_changing_switches():
                 offenders.append((fn, ln, line.strip()))
     allowed = {"ctx.hip", "fullprover.cpp"}        # from_env + the host pool's size; the facade's K16_DEVICE(S) / K16_LOG at construction
     lab_only = [o for o in offenders if o[0] not in allowed]
-    # what is left outside those files sits behind #ifdef K16_LAB / K16_TESTING
+    # what is left outside those files sits behind #ifdef K16_LAB / K16_TESTING -- or belongs to the RCCL leg, which has no
+    # context when it loads the library (k16_rank_comm_unique_id): K16_RCCL_LIB is read once per process, the gather's
+    # time limit once per communicator; neither selects a result
     for fn, ln, line in lab_only:
-        assert "K16_LAB" in line or "K16_FAULT_INJECT" in line, (fn, ln, line)
+        assert "K16_LAB" in line or "K16_FAULT_INJECT" in line or \
+            (fn == "msm_sharded.hip" and ("K16_RCCL_LIB" in line or "K16_RANK_COMM_TIMEOUT_MS" in line)), (fn, ln, line)
+
+
+def test_rccl_test_double_is_not_part_of_the_product():
+    """tests/cpp/fake_rccl.cpp stands in for RCCL in tests/test_gpu_rank_comm.py only: neither the shared library, the testing
+    build nor the static archive contains it, links any RCCL, or exports an nccl* symbol (RCCL is dlopen'ed at the first use)."""
+    for name in ("libk16.so", "libk16_testing.so", "libk16.a"):
+        path = os.path.join(PKG, name)
+        assert os.path.exists(path), path
+        blob = open(path, "rb").read()
+        assert b"k16_fake_rccl" not in blob and b"fake rccl" not in blob, name
+        if name.endswith(".so"):
+            dyn = subprocess.check_output(["readelf", "-d", path]).decode()
+            assert "rccl" not in dyn and "nccl" not in dyn, name
+            syms = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+            assert " nccl" not in syms and "ncclAllGather" not in syms.replace("k16_", ""), name
+    mk = open(os.path.join(PKG, "Makefile")).read()
+    assert "fake_rccl" not in mk
 
 
 @pytest.mark.gpu

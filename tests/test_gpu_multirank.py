@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _bench(args, env_extra, timeout=900):
     env = dict(os.environ, **env_extra)
+    env.setdefault("K16_BENCH_NO_CONFIG_LEGS", "1")     # (the config 4 / 5 legs have tests of their own below)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
@@ -85,3 +86,28 @@ def test_bench_one_process_sharded_msm():
     d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--mode", "strong", "--total-log2n", "22", "--proofs", "0",
                 "--no-cpu-baseline"], {"K16_BENCH_SHARDS": "2", "K16_BENCH_PREWARM": "1"})
     assert d["result_checked"] is True and "k16_msm_sharded" in d["config"]["sharding"]
+
+
+def test_bench_config_legs_on_two_ranks_sharing_the_gpu():
+    """The two secondary legs bench.py adds to its line at every N (BASELINE config 4: the 64-proof wave, proof j on rank
+    j mod N, one k16_verify_batch of all of them on rank 0; config 5: ONE MSM cut over the ranks, partials exchanged and
+    folded, closed form over all ranks' rows) on two ranks of the one-GPU test rig, at reduced sizes (a 2 % circuit, 2^18
+    points) so that two ranks fit the box's time budget.  The full sizes run at N = 1 in the driver's bench and in
+    test_config5_2p26_eight_shards_closed_form / test_config4_wave_of_64_distinct_proofs_one_verification_batch."""
+    d = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "14", "--proofs", "0", "--no-cpu-baseline"],
+               {"K16_BENCH_SHARE_GPU": "1", "K16_BENCH_PREWARM": "1", "K16_BENCH_NO_CONFIG_LEGS": "", "K16_BENCH_WAVE_SCALE": "0.02",
+                "K16_BENCH_2P26_LOG2N": "18", "K16_BENCH_WAVE": "16"})
+    w, s5 = d["config4_wave"], d["strong_2p18"]
+    assert w["ranks_seen"] == 2 and w["proofs"] == 16 and w["all_accepted"] and w["wrong_inputs_rejected"] and w["distinct"]
+    assert s5["ranks_seen"] == 2 and s5["shards"] == 2 and s5["result_checked"] is True
+    assert s5["host_scalars"]["points_per_s"] > 0 and s5["device_scalars"]["points_per_s"] > 0
+
+
+def test_bench_config_legs_single_rank_small():
+    """N = 1 form of the same legs (eight shards in one process; two provers sharing one resident key), reduced sizes."""
+    d = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--log2n", "14", "--proofs", "0", "--no-cpu-baseline"],
+               {"K16_BENCH_PREWARM": "1", "K16_BENCH_NO_CONFIG_LEGS": "", "K16_BENCH_WAVE_SCALE": "0.06", "K16_BENCH_2P26_LOG2N": "20",
+                "K16_BENCH_WAVE": "12", "K16_BENCH_NO_COLD": "1"})
+    w, s5 = d["config4_wave"], d["strong_2p20"]
+    assert w["all_accepted"] and w["two_provers_one_gpu"]["all_accepted"] and w["two_provers_one_gpu"]["shared_resident_key"]
+    assert s5["shards"] == 8 and s5["result_checked"] is True and "k16_msm_sharded_run: 8 shards" in s5["entry"]

@@ -1094,6 +1094,20 @@ def test_compact_witness_hand_off(tmp_path):
         assert e.value.rc == -3
         n_wide = _fill_compact(p, w)
         assert p.prove_compact(n_wide, r, s) == want     # and the prover is fine afterwards
+        # a bad compact call directly followed by a witness whose wide values overflow the packer's lists (the
+        # plain-copy branch, which never runs the list kernel): the flag of the failed call must not fail this proof
+        n_wide = _fill_compact(p, w)
+        idx[2] = n_vars + 9
+        with pytest.raises(k16.K16Error):
+            p.prove_compact(n_wide, r, s)
+        wfull = np.zeros((n_vars, 32), dtype=np.uint8)
+        wfull[:, :31] = rs.randint(0, 256, size=(n_vars, 31))
+        wfull[:, 1] |= 1                                 # every wire >= 256: more wide values than the lists hold
+        wfull[0] = 0
+        wfull[0, 0] = 1
+        with open(wt, "wb") as fh:
+            fh.write(b"wtns" + struct.pack("<II", 2, 2) + zb._section(1, sec1) + zb._section(2, wfull.tobytes()))
+        assert p.prove_mem(wfull, r, s) == ol.prove_files(zk, wt, r, s, nthreads=8)
         p.close()
         # a small circuit uploads plainly: no compact buffers
         zb.build_zkey(zk, 300, 1, 512, 900, seed=38)

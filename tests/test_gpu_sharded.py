@@ -127,3 +127,111 @@ def test_rank_comm_world_of_one_through_rccl(ctx):
         assert ol.pt_eq(1, x2, part2)
     finally:
         rc.close()
+
+
+@pytest.mark.parametrize("group", [0, 1])
+def test_pieced_pipeline_many_small_pieces_equals_the_oracle(group):
+    """the pieced host-scalar pipeline of k16_msm_sharded_run (msm_sharded.hip sharded_run: pieces uploaded through
+    lane 0 while up to two earlier pieces' MSMs run on lanes 1 / 2, offset slices of the prepared table, the per-piece fold)
+    only starts above 2^22 rows per shard at the default piece size -- k16_msm_sharded_set_piece_rows makes it run at test
+    sizes: 5+ pieces per shard, the three-in-flight branch included, host and resident scalars, against the oracle's multiexp."""
+    import k16
+    n = 11003 if group == 0 else 3001
+    bases = ol.gen_points(group, 3, n)
+    bases[7] = 0
+    sm = k16.ShardedMsm(_devices(k16, 2), group, n)
+    try:
+        sm.set_bases(bases)
+        with pytest.raises(k16.K16Error):
+            sm.set_piece_rows(5, 0)                           # below 64 rows
+        with pytest.raises(k16.K16Error):
+            sm.set_piece_rows(0, (1 << 24) + 1)
+        for kind, host_rows, dev_rows in (("full256", 1024, 2048), ("witness", 700, 64), ("uniform", 5501, 5500)):
+            sm.set_piece_rows(host_rows if group == 0 else max(64, host_rows // 4), dev_rows if group == 0 else max(64, dev_rows // 4))
+            sc = np_scalars(31 + len(kind), n, kind)
+            want = ol.msm(group, bases, sc, nthreads=4)[1]
+            assert sm.run(sc)[1] == want, (kind, "host")
+            ds = []
+            for r in range(2):
+                lo, hi = sm.shard_range(r)
+                ds.append(sm.shard_ctx(r).to_device(sc[lo:hi]))
+            assert sm.run_device(ds)[1] == want, (kind, "device")
+            for d in ds:
+                d.free()
+        sm.set_piece_rows(0, 0)                               # defaults again: one piece per shard
+        sc = np_scalars(77, n, "full256")
+        assert sm.run(sc)[1] == ol.msm(group, bases, sc, nthreads=4)[1]
+    finally:
+        sm.close()
+
+
+def test_a_failing_piece_drains_the_pieces_in_flight(tmp_path):
+    """A piece that fails with two earlier pieces' MSMs still in flight (K16_FAULT_INJECT=shard_piece:k, testing build of the
+    library only): the run returns the error, k16_msm_abort_all has drained the shard's context (nothing pending), and the
+    next run on the same object is correct.  The production library ignores the variable."""
+    import subprocess
+    code = r'''
+import os, sys
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(pkg)r)
+import numpy as np
+import k16, oracle_lib as ol
+from gpu_common import np_scalars
+testing = os.path.basename(k16.LIB_PATH) == "libk16_testing.so"
+n = 9000
+bases = ol.gen_points(0, 3, n)
+sc = np_scalars(5, n, "full256")
+want = ol.msm(0, bases, sc, nthreads=4)[1]
+sm = k16.ShardedMsm([0, 0], k16.G1, n)
+sm.set_bases(bases)
+sm.set_piece_rows(512, 512)
+assert sm.run(sc)[1] == want
+for piece in (0, 2, 5):
+    os.environ["K16_FAULT_INJECT"] = "shard_piece:%%d" %% piece
+    if testing:
+        try:
+            sm.run(sc)
+            raise AssertionError("the injected fault did not surface")
+        except k16.K16Error as e:
+            assert e.rc == -2 and "fault injected" in str(e), (e.rc, str(e))
+    else:
+        assert sm.run(sc)[1] == want
+    del os.environ["K16_FAULT_INJECT"]
+    for r in range(2):
+        assert sm.shard_ctx(r).msm_pending() == 0
+    assert sm.run(sc)[1] == want
+sm.close()
+print("shard fault child OK", "testing" if testing else "production")
+''' % {"tests": os.path.join(ROOT, "tests"), "pkg": os.path.join(ROOT, "keyless-zk-proofs_amd")}
+    for lib in ("libk16_testing.so", "libk16.so"):
+        env = dict(os.environ, K16_LIB_PATH=os.path.join(ROOT, "keyless-zk-proofs_amd", lib))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0 and "shard fault child OK" in out.stdout, out.stdout[-1000:] + out.stderr[-3000:]
+
+
+def test_config5_2p26_eight_shards_closed_form():
+    """BASELINE config 5 at its stated size in the form one box allows: ONE 2^26-point G1 MSM cut into EIGHT shards
+    (k16_msm_sharded_*: eight contexts, on device 0 when the box has one GPU, spread over the devices otherwise), every shard
+    makes ITS slice of the table on its own device ((lo + i + 1) * G), the 2 GiB of scalars arrive in host memory and are
+    uploaded in pieces inside the run, host-side EC-add fold; result == (sum_i s_i (i + 1)) * G -- the closed form of the
+    reference's own MSM test (alt_bn128_test.cpp:172-212) at the size of ParallelMultiexp's stress case
+    (RS/multiexp.cpp:183-245)."""
+    import bench
+    import k16
+    n = 1 << 26
+    sm = k16.ShardedMsm(_devices(k16, 8), k16.G1, n)
+    try:
+        assert sm.count() == 8
+        for r in range(8):
+            lo, hi = sm.shard_range(r)
+            assert hi - lo == 1 << 23
+            d = sm.shard_ctx(r).synth_points(k16.G1, lo, hi - lo)
+            sm.set_bases_device(r, d)
+            d.free()
+        scalars = bench.fast_scalars(n, seed=26)
+        xyzz, aff = sm.run(scalars)
+        ms = sm.last_ms()
+        k = bench.weighted_sum_mod_r(scalars, 0)
+        assert aff == bench.scalar_times_g(sm.shard_ctx(0), k16, k)
+        assert 0 < ms["fold_ms"] < ms["total_ms"] < 60000
+    finally:
+        sm.close()

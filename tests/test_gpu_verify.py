@@ -190,6 +190,160 @@ def test_config4_wave_of_distinct_witnesses_through_the_fullprover_pool(ctx, tmp
     V.close()
 
 
+@pytest.fixture(scope="module")
+def keyless_valid_key(ctx, tmp_path_factory):
+    """ONE valid synthetic key of the Keyless shape (18 s of host big-integer work) for the round-6 pool / wave tests."""
+    import valid_key_builder as vkb
+    key = vkb.build(_gpu_points(ctx), 1209229, 107487, 26870, seed=17)
+    assert (key["n_vars"], key["domain"]) == (1343588, 1 << 21)
+    zk = str(tmp_path_factory.mktemp("valid_key") / "keyless_valid.zkey")
+    open(zk, "wb").write(key["zkey"])
+    key["zkey"] = None          # (0.9 GB: the file is what the provers read)
+    return key, zk
+
+
+def test_provers_sharing_one_resident_key(ctx, keyless_valid_key):
+    """k16_prover_create_shared (include/k16.h): a second prover of the same key on the same device shares
+    the first one's read-only device data by reference count instead of uploading and preparing 2.7 GB again.  At the Keyless
+    shape: created in a fraction of the first one's time; its proofs are byte-equal to the first prover's (injected (r, s))
+    and verify; both prove concurrently; the shared part outlives the prover that uploaded it.
+    Replaces the per-instance zkey mapping of RS/fullprover.cpp:136-181."""
+    import threading
+    import time
+    import k16
+    key, zk = keyless_valid_key
+    c1, c2, c3 = k16.Context(0), k16.Context(0), k16.Context(0)
+    try:
+        t0 = time.perf_counter()
+        p1 = k16.Prover(c1, zk)
+        t_first = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        p2 = k16.Prover(c2, zk, share_key_of=p1)
+        t_shared = time.perf_counter() - t0
+        assert p2.info() == p1.info()
+        assert t_shared < 0.5 * t_first and t_shared < 0.6, (t_first, t_shared)     # (includes its warm-up proof)
+        with pytest.raises(k16.K16Error):
+            k16.Prover(c1, zk, share_key_of=p1)                                      # needs a context of its own
+        V = k16.VerifyingKey(ctx, key["vk"])
+        import valid_key_builder as vkb
+        w, pub = vkb.fast_witness(key["shape"], 901)
+        r, s = pm.limbs(pm.SplitMix64(71).below(pm.R)), pm.limbs(pm.SplitMix64(72).below(pm.R))
+        a = p1.prove_mem(w, r, s)
+        assert p2.prove_mem(w, r, s) == a
+        assert V.verify_batch([gio.proof_from_json(a)], [pub]) == [True]
+        # both at once, distinct witnesses, CSPRNG blinding: every proof verifies with ITS input
+        wits = [vkb.fast_witness(key["shape"], 910 + i) for i in range(4)]
+        out = [[None] * 4, [None] * 4]
+
+        def work(k, pv):
+            for i in range(4):
+                out[k][i] = pv.prove_mem(wits[(i + k) % 4][0])
+
+        th = [threading.Thread(target=work, args=(k, pv)) for k, pv in enumerate((p1, p2))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        proofs = [gio.proof_from_json(out[k][i]) for k in range(2) for i in range(4)]
+        ins = [wits[(i + k) % 4][1] for k in range(2) for i in range(4)]
+        assert V.verify_batch(proofs, ins) == [True] * 8
+        # the prover that uploaded the key goes first: the shared part stays until its last user has gone
+        p1.close()
+        c1.close()
+        assert p2.prove_mem(w, r, s) == a
+        p3 = k16.Prover(c3, zk, share_key_of=p2)
+        p2.close()
+        assert p3.prove_mem(w, r, s) == a
+        p3.close()
+        V.close()
+    finally:
+        for c in (c3, c2):
+            c.close()
+
+
+def test_fullprover_pool_compact_hand_off_and_shared_key(ctx, tmp_path, keyless_valid_key):
+    """The compact witness hand-off THROUGH THE POOL (k16_fullprover_compact_lease / _prove_compact, include/k16.h) on ONE
+    FullProver whose two provers share device 0 and one resident key (K16_DEVICES=0,0): three concurrent callers lease a slot,
+    write their witness into ITS pinned buffers and prove on it; every proof of the valid Keyless-shape key verifies with its
+    own public input.  Replaces the temp-file hand-off of RS/fullprover.cpp:204-250 / prover_handler.rs:511-527."""
+    import os
+    import subprocess
+    import k16
+    import valid_key_builder as vkb
+    from test_boundary import build_harness
+    key, zk = keyless_valid_key
+    n_wit = 6
+    paths, inputs = [], []
+    for i in range(n_wit):
+        w, pub = vkb.fast_witness(key["shape"], 700 + i)
+        paths.append(str(tmp_path / ("c%02d.wtns" % i)))
+        vkb.write_wtns(paths[-1], w)
+        inputs.append(pub)
+    exe = build_harness(tmp_path)
+    env = dict(os.environ, K16_DEVICES="0,0", K16_HARNESS_MEM="compact")
+    out = subprocess.run([exe, zk, ",".join(paths), "2", "3"], capture_output=True, text=True, timeout=900, env=env)
+    lines = out.stdout.splitlines()
+    assert lines[0] == "state=0", out.stderr[-2000:]
+    proofs = [None] * n_wit
+    us = []
+    for k in range(n_wit):
+        head = lines[1 + 2 * k]
+        assert head.startswith("type=0 error=0 ms="), lines[:8]
+        us.append(int(head.split("ms=")[1].split()[0]))          # (compact mode: microseconds of the prove call alone)
+        proofs[int(head.split("wtns=")[1])] = gio.proof_from_json(lines[2 + 2 * k])
+    assert all(p is not None for p in proofs) and len(set(proofs)) == n_wit
+    V = k16.VerifyingKey(ctx, key["vk"])
+    assert V.verify_batch(proofs + [proofs[0]], inputs + [inputs[1]]) == [True] * n_wit + [False]
+    V.close()
+    assert 1000 < min(us) < 60000, us
+
+
+def test_config4_wave_of_64_distinct_proofs_one_verification_batch(ctx, keyless_valid_key):
+    """BASELINE config 4 at its stated wave size on whatever the box has: 64 DISTINCT witnesses of a valid Keyless-shape key
+    (nVars 1,343,588, N = 2^21), one prover per visible GPU (two sharing device 0 and one resident key on a one-GPU box),
+    every proof accepted by ONE k16_verify_batch with its own public input, and rejected with its neighbour's.
+    The service's loop: prover_handler.rs:244-345."""
+    import threading
+    import k16
+    import valid_key_builder as vkb
+    key, zk = keyless_valid_key
+    wits = [vkb.fast_witness(key["shape"], 3000 + i) for i in range(64)]
+    assert len({tuple(w[1]) for w in wits}) == 64
+    ndev = max(1, k16.load().k16_device_count())
+    devs = list(range(ndev)) if ndev > 1 else [0, 0]
+    ctxs = [k16.Context(d) for d in devs]
+    provers = []
+    for c, d in zip(ctxs, devs):
+        sib = next((pv for pv, dd in zip(provers, devs) if dd == d), None)
+        provers.append(k16.Prover(c, zk, share_key_of=sib))
+    jobs, out, lock = list(range(64)), [None] * 64, threading.Lock()
+
+    def worker(pv):
+        while True:
+            with lock:
+                if not jobs:
+                    return
+                j = jobs.pop(0)
+            out[j] = pv.prove_mem(wits[j][0])
+
+    th = [threading.Thread(target=worker, args=(pv,)) for pv in provers]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    proofs = [gio.proof_from_json(js) for js in out]
+    assert len(set(proofs)) == 64
+    V = k16.VerifyingKey(ctx, key["vk"])
+    assert V.verify_batch(proofs, [w[1] for w in wits]) == [True] * 64
+    assert V.verify_batch(proofs, [wits[(j + 1) % 64][1] for j in range(64)]) == [False] * 64
+    assert ol.groth16_verify(key["vk"], proofs[37], wits[37][1])
+    V.close()
+    for pv in provers:
+        pv.close()
+    for c in ctxs:
+        c.close()
+
+
 def _neg_g2(q):
     """-(x, y) for an affine Montgomery G2 point (Montgomery form is linear: -yR = p - yR)."""
     q = bytes(q)

@@ -109,3 +109,43 @@ def test_pipelined_exchanges_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _worker_exchange_fails_everywhere(rank, world, port, q):
+    """a RankExchange whose id cannot be made on rank 0 (no loadable RCCL) must fail on EVERY rank, after the
+    broadcast, so that the fallback agreement that follows (bench.py: all_reduce(MIN)) is reached by all of them."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      K16_RCCL_LIB="/nonexistent/librccl.so.1")
+    for p in (HERE, os.path.join(ROOT, "keyless-zk-proofs_amd")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    msg = None
+    try:
+        sharding.RankExchange(dist, None)
+    except RuntimeError as e:
+        msg = str(e)
+    ok = torch.tensor([0 if msg else 1])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # the agreement bench.py makes next: must not hang or mismatch
+    q.put((rank, msg, int(ok.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_exchange_fails_on_all_ranks_or_none_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange_fails_everywhere, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, msg, agreed in res:
+        assert msg and "rank 0 could not create the communicator id" in msg and "dlopen librccl" in msg, (rank, msg)
+        assert agreed == 0

@@ -161,9 +161,36 @@ def build(points, n_bits, n_bytes, n_prod, seed=1):
     zkey = b"zkey" + struct.pack("<II", 1, len(secs)) + b"".join(secs)
     vk = dict(alpha1=bytes(hdr1[0]), beta2=bytes(hdr2[0]), gamma2=bytes(hdr2[1]), delta2=bytes(hdr2[2]),
               ic=[bytes(pic[i]) for i in range(n_public + 1)])
+    shape = dict(n_vars=n_vars, bit0=bit0, byte0=byte0, prod0=prod0, prods=prods)
     return dict(zkey=zkey, vk=vk, witness=witness_bytes(w), public=[w[1]], n_vars=n_vars, n_public=n_public, domain=N,
-                n_coefs=len(coefs),
+                n_coefs=len(coefs), shape=shape,
                 new_witness=lambda wseed: (lambda ww: (witness_bytes(ww), [ww[1]]))(make_witness(wseed)))
+
+
+def fast_witness(shape, wseed):
+    """A satisfying assignment of the circuit `shape` (build()['shape']: picklable, so that every rank of a multi-GPU run can
+    make its own witnesses) as ((n_vars, 32) uint8, [public input]): the free wires from numpy's generator (1.3 M Python
+    big-int draws per witness are what make build()['new_witness'] take seconds), the product wires computed exactly."""
+    n_vars, bit0, byte0, prod0 = shape["n_vars"], shape["bit0"], shape["byte0"], shape["prod0"]
+    rs = np.random.RandomState(wseed & 0x7FFFFFFF)
+    w = np.zeros((n_vars, 32), dtype=np.uint8)
+    w[0, 0] = 1
+    pub = (int.from_bytes(rs.bytes(8), "little") | 1)
+    w[1, :8] = np.frombuffer(pub.to_bytes(8, "little"), dtype=np.uint8)
+    w[bit0:byte0, 0] = rs.randint(0, 2, size=byte0 - bit0)
+    w[byte0:prod0, 0] = rs.randint(0, 256, size=prod0 - byte0)
+    val = {}
+
+    def get(i):
+        if i >= prod0:
+            return val[i]
+        return pub if i == 1 else int(w[i, 0])
+
+    for c, a, b, d, k1, k2, k3 in shape["prods"]:
+        v = (k1 * get(a) + k2 * get(b)) % R * (k3 * get(d) % R) % R
+        val[c] = v
+        w[c] = np.frombuffer(v.to_bytes(32, "little"), dtype=np.uint8)
+    return w, [pub]
 
 
 def oracle_points(group, scalars):
