@@ -769,7 +769,8 @@ def config4_wave_leg(k16, torch, dist, rank, world, dev, wave, scale):
                    "distinct": bool(distinct), "proofs_per_s_proved_and_verified": wave / (elapsed + t_verify),
                    "setup_s": {"build_valid_key": t_key, "witnesses": t_wit}}
             if two is not None:
-                pr2 = [gio.proof_from_json(two.pop("_proofs")[j]) for j in order]
+                js2 = two.pop("_proofs")
+                pr2 = [gio.proof_from_json(js2[j]) for j in order]
                 two["all_accepted"] = bool(all(V.verify_batch(pr2, ins)))
                 out["two_provers_one_gpu"] = two
                 if not two["all_accepted"]:
@@ -1348,7 +1349,9 @@ def main():
                          else "prepared once (k16_msm_bases_prepare)" if prepared is not None
                          else "reference format (Montgomery affine), converted inside every step",
                 "sharding": ("contiguous shards (sharding.shard_range) + %s all_gather of 128-B partials + EC-add fold"
-                             % ("gloo (test rig: all ranks on GPU 0)" if SHARE_GPU else
+                             % ("libk16.so's k16_rank_comm_* (ncclAllGather) over the RCCL test double (test rig: all ranks on GPU 0)"
+                                if (c_exchange is not None and SHARE_GPU) else
+                                "gloo (test rig: all ranks on GPU 0)" if SHARE_GPU else
                                 "RCCL through libk16.so's k16_rank_comm_* (ncclAllGather)" if c_exchange is not None else
                                 "RCCL (torch.distributed)")) if dist is not None else
                             ("single GPU" if shards_obj is None else

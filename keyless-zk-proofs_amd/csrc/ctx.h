@@ -34,6 +34,12 @@ struct k16_ntt_table {
     uint32_t  s      = 0; // log2 size
     k16::Fr*  roots  = nullptr; // device, 2^s entries, canonical Montgomery (R = 2^256)
     uint32_t* roots9 = nullptr; // device, the same roots as R' values (x * 2^261 mod r, < 2r) in nine 29-bit limbs each (36 bytes), see ntt.hip
+    // Round 6: the twiddles of the LATE stages once more, stage-major and contiguous (ntt.hip k_build_stage9): stage s' >= 17 of a
+    // transform uses root(s', j) = roots[j << (s - s')] for j < 2^(s'-1) -- consecutive butterflies read entries 2^(s - s')
+    // apart, a 36-byte gather with a stride of 72 B ... 1.1 KB over a 151 MB table (4 M loads per 2^21 transform, as many bytes
+    // as the data itself).  stage9 holds root(s', j) at entry 2^(s'-1) - 2^16 + j for 17 <= s' < s: 32 consecutive butterflies
+    // read 1152 contiguous bytes.  Null for tables below 2^18 or with K16_NTT_NO_STAGE_TABLES.
+    uint32_t* stage9 = nullptr;
     k16::Fr   pow2inv[34];
     k16::Fq9  pow2inv9[34];     // 2^-k as Fr9
 };
@@ -47,10 +53,14 @@ struct k16_ntt_table {
 // into the lab / testing builds (-DK16_LAB, -DK16_TESTING).
 struct k16_tuning {
     bool     atomic_sort = false, no_fused_convert = false, no_staged_sort = false, fused_bins = false, x8 = false;
-    bool     no_l1_prefetch = false, ntt_tail_small = false, ntt_unfused = false;
+    bool     no_l1_prefetch = false, ntt_tail_small = false, ntt_unfused = false, ntt_no_stage_tables = false;
     bool     no_fixed_base = false, no_stream_priority = false, b_sort = false, b_derive = false, no_skip_zero_rows = false;
     bool     classes = false, no_warmup = false, spmv_full = false, fused_hscalars = false, no_split_classes = false;
     bool     b2_first = false, no_acc_skip = false;
+    // round 6 scheduling experiments (identical results): lane of the H MSM (default 1, behind C's MSM), lane of
+    // the B1 MSM (default 0, behind A's), the H MSM's wait for the chain issued behind its sort's memset instead of in front
+    int      h_lane = 1, b1_lane = 0, witness_seg = 0; // witness_seg: segment length of the witness MSMs' accumulations (default 32)
+    bool     h_wait_first = false;
     bool     trace = false, trace_enq = false, trace_host = false, verify_no_coop = false, verify_coop_trace = false;
     int      seg = 0, wsum_mlog = -1, witness_c = 0, ntt_tile_log = 0, narrow_chain = 0, narrow_chain_g2 = 0;
     uint64_t verify_coop_max = 2048;
@@ -101,6 +111,7 @@ struct k16_ctx {
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
+    hipEvent_t wait_after_memset = nullptr; // one-shot: the next bucket sort waits for this event BEHIND its tables' memset
     void* pinned = nullptr;     // small pinned host staging buffer (coherent, mapped into the device's address space)
     void* pinned_dev = nullptr; // its device-side address: the last kernel of an MSM writes its <= 240 partial sums straight
                                 // into the staging slot (a hipMemcpyAsync D2H was observed to BLOCK the enqueuing thread for

@@ -66,6 +66,7 @@ k16_tuning k16_tuning::from_env()
     t.no_l1_prefetch     = on("K16_NO_L1_PREFETCH");
     t.ntt_tail_small     = on("K16_NTT_TAIL_SMALL");
     t.ntt_unfused        = on("K16_NTT_UNFUSED");
+    t.ntt_no_stage_tables = on("K16_NTT_NO_STAGE_TABLES");
     t.no_fixed_base      = on("K16_NO_FIXED_BASE");
     t.no_stream_priority = on("K16_NO_STREAM_PRIORITY");
     t.b_sort             = onv("K16_B_SORT");
@@ -78,6 +79,10 @@ k16_tuning k16_tuning::from_env()
     t.no_split_classes   = on("K16_NO_SPLIT_CLASSES");
     t.b2_first           = on("K16_B2_FIRST");
     t.no_acc_skip        = on("K16_NO_ACC_SKIP");
+    t.h_lane             = std::max(1, std::min(k16_ctx::N_LANES - 1, num("K16_H_LANE", 1)));
+    t.b1_lane            = std::max(0, std::min(k16_ctx::N_LANES - 1, num("K16_B1_LANE", 0)));
+    t.h_wait_first       = onv("K16_H_WAIT_FIRST");
+    t.witness_seg        = std::max(0, std::min(1024, num("K16_WITNESS_SEG", 0)));
     t.trace              = on("K16_TRACE");
     t.trace_enq          = on("K16_TRACE_ENQ");
     t.trace_host         = on("K16_TRACE_HOST");
@@ -166,6 +171,8 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
         if (kv.second.roots) (void)hipFree(kv.second.roots);
     for (auto& kv : c->ntt_tables)
         if (kv.second.roots9) (void)hipFree(kv.second.roots9);
+    for (auto& kv : c->ntt_tables)
+        if (kv.second.stage9) (void)hipFree(kv.second.stage9);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (int i = 0; i < k16_ctx::PEND_SLOTS; i++)
         if (c->pend_ev[i]) (void)hipEventDestroy(c->pend_ev[i]);

@@ -122,6 +122,33 @@ __device__ __forceinline__ Fr9 ld_tw9(const uint32_t* __restrict__ tw, size_t i)
     for (int k = 0; k < 9; k++) r.l[k] = p[k];
     return r;
 }
+// root(sp, j) -- the twiddle of butterfly j of stage sp (fft.hpp:40-43) -- from the stage-major copy of the late stages where
+// there is one (k16_ntt_table::stage9: contiguous in j), from the root table otherwise (stride 2^(S - sp)).  The choice is
+// uniform over a workgroup's double stage.
+constexpr uint32_t STAGE9_LO = 17;
+__device__ __forceinline__ Fr9 ld_stage_tw9(const uint32_t* __restrict__ roots9, const uint32_t* __restrict__ stage9, uint32_t S,
+                                            uint32_t sp, size_t j)
+{
+#ifdef K16_LAB_NTT_TW0 // lab builds only (build_alt.sh NAME -DK16_LAB_NTT_TW0=<first stage> ntt): every twiddle of the stages from
+    // that one on is root 0 -- WRONG transforms on purpose: what a pass costs when its twiddle loads all hit one cache line
+    if (sp >= (K16_LAB_NTT_TW0)) j = 0;
+#endif
+    if (stage9 && sp >= STAGE9_LO && sp < S) return ld_tw9(stage9, ((size_t)1 << (sp - 1)) - ((size_t)1 << (STAGE9_LO - 1)) + j);
+    return ld_tw9(roots9, j << (S - sp));
+}
+// stage9[2^(sp-1) - 2^16 + j] = roots9[j << (S - sp)] for STAGE9_LO <= sp < S, j < 2^(sp-1)
+__global__ void __launch_bounds__(256) k_build_stage9(uint32_t* __restrict__ stage9, const uint32_t* __restrict__ roots9, uint32_t S,
+                                                      uint64_t entries)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    const uint64_t v  = e + ((uint64_t)1 << (STAGE9_LO - 1)); // in [2^(sp-1), 2^sp)
+    const uint32_t sp = 64u - (uint32_t)__clzll((long long)v);
+    const uint64_t j  = v - ((uint64_t)1 << (sp - 1));
+    const uint32_t* src = roots9 + (j << (S - sp)) * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) stage9[e * 9 + k] = src[k];
+}
 // Up to three polynomials per launch (blockIdx.y): the prover's a / b / c chains are independent, and a pass of one
 // polynomial spends a quarter of its time filling and draining the chip (all resident workgroups load before any computes).
 struct NttPtrs {
@@ -136,7 +163,8 @@ struct NttPtrs {
 // with one element of padding per tile row so that the LDS reads stay conflict-free.
 template <bool CONV_IN, bool CONV_OUT, bool TAIL, int THREADS = 256>
 __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_t* __restrict__ roots9, uint32_t s0, uint32_t K,
-                                                   uint32_t TL, uint32_t S, uint32_t logn, const Fr* __restrict__ shift9)
+                                                   uint32_t TL, uint32_t S, uint32_t logn, const Fr* __restrict__ shift9,
+                                                   const uint32_t* __restrict__ stage9)
 {
     __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     extern __shared__ uint4 ntt_lds[];
@@ -176,7 +204,7 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
             const size_t   j  = ((size_t)ml << s0) + lo0 + tl;
             Fr9            x1 = at(m1 * RS + tl);
             Fr9            u  = at(m0 * RS + tl);
-            Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_tw9(roots9, j << (S - s0 - t)), x1); // s0 == 0: the twiddle is 1
+            Fr9            tt = (s0 == 0) ? x1 : frmul9(ld_stage_tw9(roots9, stage9, S, s0 + t, j), x1); // s0 == 0: the twiddle is 1
             at(m0 * RS + tl) = fadd9(u, tt);
             at(m1 * RS + tl) = fsub9_t<Fr9C, 2>(u, tt);
         }
@@ -204,7 +232,7 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
                 p1 = x1;
                 p3 = x3;
             } else {
-                Fr9 w1 = ld_tw9(roots9, ja << (S - s0 - t));
+                Fr9 w1 = ld_stage_tw9(roots9, stage9, S, s0 + t, ja);
                 p1     = frmul9(w1, x1);
                 p3     = frmul9(w1, x3);
             }
@@ -223,8 +251,8 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
                 a2 = fadd9_lazy(x2, p3);
                 a3 = fsub9_lazy4_t<Fr9C>(x2, p3);
             }
-            Fr9 q2 = unit ? a2 : frmul9(ld_tw9(roots9, ja << (S - s0 - t - 1)), a2);
-            Fr9 q3 = frmul9(ld_tw9(roots9, jb << (S - s0 - t - 1)), a3);
+            Fr9 q2 = unit ? a2 : frmul9(ld_stage_tw9(roots9, stage9, S, s0 + t + 1, ja), a2);
+            Fr9 q3 = frmul9(ld_stage_tw9(roots9, stage9, S, s0 + t + 1, jb), a3);
             at(i0)          = fadd9(a0, q2);
             // unit: q2 = a2 = x2 + x3 is not fresh from a multiplication -- up to 4r, so the offset must be 4r (with 2r the
             // difference goes negative when x2, x3 >= r and x0 + x1 is small: about once per 10^3 proofs of 2^21 with
@@ -348,6 +376,16 @@ int k16_ntt_get_table(k16_ctx* ctx, uint64_t max_domain, k16_ntt_table** out)
     hipLaunchKernelGGL(k_roots_to_r9, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, ctx->stream, t.roots, t.roots9, nr);
     K16_HIP(ctx, hipGetLastError());
     for (int k = 0; k <= 33; k++) t.pow2inv9[k] = fr9_from_fr(t.pow2inv[k]);
+    if (s > STAGE9_LO) { // stage-major twiddles of stages 17 .. s - 1 (see k16_ntt_table::stage9): 73 MB for the prover's 2^22 table
+        const uint64_t entries = ((uint64_t)1 << (s - 1)) - ((uint64_t)1 << (STAGE9_LO - 1));
+        if (hipMalloc((void**)&t.stage9, (size_t)entries * 36) == hipSuccess) {
+            hipLaunchKernelGGL(k_build_stage9, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, ctx->stream, t.stage9, t.roots9, s, entries);
+            K16_HIP(ctx, hipGetLastError());
+        } else {
+            (void)hipGetLastError(); // no room: the passes read the root table (same values)
+            t.stage9 = nullptr;
+        }
+    }
     auto ins = ctx->ntt_tables.emplace(s, t);
     *out     = &ins.first->second;
     return K16_OK;
@@ -362,8 +400,9 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
         pp.src[i] = polys[i];
         pp.dst[i] = tail_dst ? tail_dst[i] : nullptr;
     }
-    const uint64_t n  = 1ull << logn;
-    uint32_t       s0 = 0;
+    const uint64_t  n      = 1ull << logn;
+    uint32_t        s0     = 0;
+    const uint32_t* stage9 = ctx->tune.ntt_no_stage_tables ? nullptr : tab->stage9;
     // Tile size.  1024 elements (36 KB of LDS, four workgroups per CU): 21 stages are three passes (10 + 6 + 5, 512-byte runs).
     // K16_NTT_TILE_LOG=11: 2048 elements (72 KB, two workgroups of 512 threads per CU), two passes (11 + 10) -- one load /
     // store round trip less per transform, but the second pass then moves 64-byte runs (T = 2: a tile is T x 2^10 elements
@@ -401,7 +440,7 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
                 attr2 = true;                                                                                                   \
             }                                                                                                                   \
             hipLaunchKernelGGL((k_ntt_pass9<CI, CO, TA, 256>), grid, dim3(256), lds_launch, st, pp, tab->roots9, s0, K, TL,     \
-                               tab->s, logn, shift9);                                                                           \
+                               tab->s, logn, shift9, stage9);                                                                   \
         } else if (big) {                                                                                                              \
             static bool attr = false;                                                                                           \
             if (!attr) {                                                                                                        \
@@ -410,10 +449,10 @@ static void ntt_passes(k16_ctx* ctx, Fr* const* polys, int count, uint32_t logn,
                 attr = true;                                                                                                    \
             }                                                                                                                   \
             hipLaunchKernelGGL((k_ntt_pass9<CI, CO, TA, 512>), grid, dim3(512), lds, st, pp, tab->roots9, s0, K, TL, tab->s,    \
-                               logn, shift9);                                                                                   \
+                               logn, shift9, stage9);                                                                           \
         } else                                                                                                                  \
             hipLaunchKernelGGL((k_ntt_pass9<CI, CO, TA, 256>), grid, dim3(256), lds, st, pp, tab->roots9, s0, K, TL, tab->s,    \
-                               logn, shift9);                                                                                   \
+                               logn, shift9, stage9);                                                                           \
     } while (0)
         if (tail)
             K16_NTT_LAUNCH(false, false, true);

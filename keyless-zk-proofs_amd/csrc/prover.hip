@@ -1066,8 +1066,9 @@ static int prove_guarded(k16_prover* p, const void* h_wtns, uint64_t n_vars, int
         (void)k16_msm_abort_all(ctx); // overwrites ctx->err only when an MSM in flight failed itself
         if (p->st2) (void)hipStreamSynchronize(p->st2);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); // (the witness expansion: it writes the packer's bad-entry flag)
-        ctx->forced_c         = 0;
-        ctx->parallel_combine = false;
+        ctx->forced_c          = 0;
+        ctx->parallel_combine  = false;
+        ctx->wait_after_memset = nullptr;
         try {
             if (!err.empty()) ctx->err = err;
         } catch (...) {
@@ -1243,7 +1244,8 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
         ForcedC(k16_ctx* cx, unsigned v) : c(cx), saved(cx->forced_c)
         {
             if (!saved && cx_big(cx, v)) c->forced_c = v;
-            c->forced_seg = 32; // witness scalars: one bucket holds ~45 % of the points, short segments keep it parallel
+            // witness scalars: one bucket holds ~45 % of the points, short segments keep it parallel (K16_WITNESS_SEG: sweep)
+            c->forced_seg = cx->tune.witness_seg ? (unsigned)cx->tune.witness_seg : 32u;
         }
         static bool cx_big(k16_ctx*, unsigned) { return true; }
         ~ForcedC()
@@ -1335,7 +1337,12 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
             if ((rc = k16_msm_enqueue_prepared(ctx, K16_G2, p->d_B2, p->d_wtns, n_wit))) return rc;
         }
         const bool b_derived = p->b_derive && !b2_lead;
-        ctx->cur_lane        = 0;
+        // K16_B1_LANE (round 6 experiment): B1 on a lane of its own instead of behind A's MSM on lane 0 -- its accumulation then
+        // starts with A's and C's (they all read lane 0's sort) and its tail runs under the chain, not after it
+        const int b1_lane = (ctx->tune.b1_lane != 0 && ctx->tune.b1_lane != 1 && ctx->tune.b1_lane != 2 &&
+                             ctx->tune.b1_lane != ctx->tune.h_lane) ? ctx->tune.b1_lane : 0;
+        if (b1_lane) K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, b1_lane), p->ev_w, 0));
+        ctx->cur_lane        = b1_lane;
         ctx->reuse_sort      = true;
         ctx->reuse_sort_lane = (p->b_sort || b_derived) ? 2 : own;
         ctx->skip_next       = b_derived ? (const uint64_t*)p->d_skip_b : skip_b;
@@ -1358,8 +1365,15 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
         return K16_ERR_HIP;
     }
     // groth16.cpp:281-283
-    ctx->cur_lane = 1;
-    K16_HIP(ctx, hipStreamWaitEvent(s1, p->ev_h, 0));
+    // K16_H_LANE (round 6 experiment): the H MSM on a lane of its own instead of behind C's MSM on lane 1;
+    // K16_H_WAIT_FIRST: its wait for the chain issued behind its sort's memset (msm_sort_launch) instead of here
+    const int   h_lane = ctx->tune.h_lane;
+    hipStream_t sh     = k16_lane_stream(ctx, h_lane);
+    ctx->cur_lane      = h_lane;
+    if (ctx->tune.h_wait_first && p->d_Htab)
+        ctx->wait_after_memset = p->ev_h;
+    else
+        K16_HIP(ctx, hipStreamWaitEvent(sh, p->ev_h, 0));
     if (p->d_Htab) {
         if (hs_in_sort) {
             ctx->hs_next[0] = p->d_t[0];

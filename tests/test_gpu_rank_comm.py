@@ -42,7 +42,8 @@ def fake(tmp_path_factory):
 
 def _spawn(fake, tmp_path, world, mode, extra_env=None, args=()):
     idfile = str(tmp_path / ("id_%d_%s_%d" % (world, mode, time.time_ns())))
-    env = dict(os.environ, K16_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_MS="30000", **(extra_env or {}))
+    env = dict(os.environ, K16_RCCL_LIB=fake, FAKE_RCCL_TIMEOUT_MS="30000")
+    env.update(extra_env or {})
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     procs = [subprocess.Popen([sys.executable, CHILD, str(r), str(world), idfile, mode] + [str(a) for a in args],
