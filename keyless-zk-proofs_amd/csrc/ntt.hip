@@ -11,6 +11,9 @@
 #include "ctx.h"
 #include "bn254_fq9.h"
 
+#ifndef K16_CHAIN_PRIO
+#define K16_CHAIN_PRIO 3 // wave priority of the polynomial chain's kernels (-D to compare)
+#endif
 using namespace k16;
 
 namespace {
@@ -48,7 +51,7 @@ __global__ void __launch_bounds__(256) k_build_roots(Fr* __restrict__ roots, uin
 // fft.cpp:170-189
 __global__ void __launch_bounds__(256) k_bitrev(Fr* __restrict__ a, uint32_t logn)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
+    __builtin_amdgcn_s_setprio(K16_CHAIN_PRIO); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1u << logn)) return;
     uint32_t r = __brev(i) >> (32 - logn);
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(THREADS) k_ntt_pass9(NttPtrs pp, const uint32_
                                                    uint32_t TL, uint32_t S, uint32_t logn, const Fr* __restrict__ shift9,
                                                    const uint32_t* __restrict__ stage9)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
+    __builtin_amdgcn_s_setprio(K16_CHAIN_PRIO); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     extern __shared__ uint4 ntt_lds[];
     uint32_t*      lds32 = reinterpret_cast<uint32_t*>(ntt_lds);
     // element e of the tile: nine dwords; the TAIL variant (which reads the tile mid-major: a stride of 9 T dwords between
@@ -295,7 +298,7 @@ __global__ void __launch_bounds__(256) k_build_shift9(Fr* __restrict__ shift9, c
 // fft.cpp:226-245 on packed R' data
 __global__ void __launch_bounds__(256) k_inv_tail9(Fr* __restrict__ a, uint32_t logn, Fr9 scale)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
+    __builtin_amdgcn_s_setprio(K16_CHAIN_PRIO); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t n = 1u << logn;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > (n >> 1)) return;

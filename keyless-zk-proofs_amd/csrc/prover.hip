@@ -34,6 +34,9 @@
 #include "bn254_fq9.h"
 #include "spmv_plan.h"
 
+#ifndef K16_CHAIN_PRIO
+#define K16_CHAIN_PRIO 3 // wave priority of the polynomial chain's kernels (-D to compare)
+#endif
 using namespace k16;
 
 namespace {
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(256) k_spmv(const SpmvSlice* __restrict__ slic
                                               Fr* __restrict__ a, Fr* __restrict__ b, uint32_t N, uint32_t logN,
                                               const uint16_t* __restrict__ n16)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
+    __builtin_amdgcn_s_setprio(K16_CHAIN_PRIO); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     Fr9            acc = fq9_zero();
     // n16 (round 4): one 16-bit word per wire -- the value when it is below 256, bit 15 when it is not.  98 % of a circuit's
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(256) k_spmv(const SpmvSlice* __restrict__ slic
 __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __restrict__ a, const Fr* __restrict__ b,
                                              uint32_t N)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
+    __builtin_amdgcn_s_setprio(K16_CHAIN_PRIO); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) st_r9(&c[i], frmul9(ld_r9(&a[i]), ld_r9(&b[i])));
 }
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(256) k_mul(Fr* __restrict__ c, const Fr* __res
 __global__ void __launch_bounds__(256) k_hscalars(Fr* __restrict__ out, const Fr* __restrict__ a,
                                                   const Fr* __restrict__ b, const Fr* __restrict__ c, uint32_t N)
 {
-    __builtin_amdgcn_s_setprio(3); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
+    __builtin_amdgcn_s_setprio(K16_CHAIN_PRIO); // the polynomial chain gates the H MSM: its waves win VALU arbitration beside the witness MSMs
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) st_fr(&out[i], fr9_to_standard(frsub9(frmul9(ld_r9(&a[i]), ld_r9(&b[i])), ld_r9(&c[i]))));
 }
@@ -1339,8 +1342,9 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
         const bool b_derived = p->b_derive && !b2_lead;
         // K16_B1_LANE (round 6 experiment): B1 on a lane of its own instead of behind A's MSM on lane 0 -- its accumulation then
         // starts with A's and C's (they all read lane 0's sort) and its tail runs under the chain, not after it
-        const int b1_lane = (ctx->tune.b1_lane != 0 && ctx->tune.b1_lane != 1 && ctx->tune.b1_lane != 2 &&
-                             ctx->tune.b1_lane != ctx->tune.h_lane) ? ctx->tune.b1_lane : 0;
+        // Default: lane 0 for a proof alone, lane 3 when other provers share the GPU (K16_OPT_SHARED_GPU).
+        const int b1_want = ctx->tune.b1_lane >= 0 ? ctx->tune.b1_lane : (ctx->shared_gpu ? 3 : 0);
+        const int b1_lane = (b1_want == 3 && ctx->tune.h_lane != 3) ? 3 : 0;
         if (b1_lane) K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, b1_lane), p->ev_w, 0));
         ctx->cur_lane        = b1_lane;
         ctx->reuse_sort      = true;

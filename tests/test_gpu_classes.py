@@ -330,7 +330,14 @@ def test_tables_that_share_their_scalars_share_or_derive_the_bucket_sort(ctx, gr
         d.free()
 
 
-@pytest.mark.parametrize("mode", ["classes", "b_sort", "b_derive", "fused_h_scalars", "b2_first"])
+OPTIONAL_PATHS = {"classes": {"K16_CLASSES": "1"}, "b_sort": {"K16_B_SORT": "1"}, "b_derive": {"K16_B_DERIVE": "1"},
+                  "fused_h_scalars": {"K16_FUSED_HSCALARS": "1"}, "b2_first": {"K16_B2_FIRST": "1"},
+                  # round 6: the scheduling switches of DESIGN.md 7b and the split G2 accumulation (k_accumulate_split)
+                  "g2_split2": {"K16_G2_ACC_SPLIT": "2"}, "g2_split4_seg16": {"K16_G2_ACC_SPLIT": "4", "K16_WITNESS_SEG": "16"},
+                  "h_lane3_wait_first": {"K16_H_LANE": "3", "K16_H_WAIT_FIRST": "1"}, "b1_lane3_seg48": {"K16_B1_LANE": "3", "K16_WITNESS_SEG": "48"}}
+
+
+@pytest.mark.parametrize("mode", list(OPTIONAL_PATHS))
 def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, monkeypatch, mode):
     """BASELINE config 3 at its stated size (nVars 1,343,588, N = 2^21, B1 / B2 half (0,0)) with the witness MSMs taking
     the paths that are off by default -- scalar classes (K16_CLASSES=1), a bucket sort of B's own without its (0,0)
@@ -339,7 +346,9 @@ def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, m
     prover."""
     import bench
     import k16
-    monkeypatch.setenv({"classes": "K16_CLASSES", "b_sort": "K16_B_SORT", "b_derive": "K16_B_DERIVE", "fused_h_scalars": "K16_FUSED_HSCALARS", "b2_first": "K16_B2_FIRST"}[mode], "1")
+    for k, v in OPTIONAL_PATHS[mode].items():
+        monkeypatch.setenv(k, v)
+    round6 = mode in ("g2_split2", "g2_split4_seg16", "h_lane3_wait_first", "b1_lane3_seg48")
     n_vars, N, n_coefs = bench.KEYLESS["n_vars"], bench.KEYLESS["domain"], bench.KEYLESS["n_coefs"]
     zk = str(tmp_path / "keyless_shape.zkey")
     wt = str(tmp_path / "keyless_shape.wtns")
@@ -349,7 +358,7 @@ def test_keyless_shape_proof_through_the_optional_witness_paths(ctx, tmp_path, m
     ctx2 = k16.Context(0)            # the switches are read when a CONTEXT is created (round 5: no getenv on any hot path)
     try:
         p = k16.Prover(ctx2, zk)
-        for seed in (100, 103):
+        for seed in ((100,) if round6 else (100, 103)):
             w = bench.synth_witness(n_vars, seed)
             bench.write_wtns(wt, w)
             assert p.prove_mem(w, r, s) == ol.prove_files(zk, wt, r, s, nthreads=os.cpu_count() or 8)
