@@ -1,11 +1,14 @@
 #!/bin/bash
-# Round 6: wave priorities inside a proof.  The polynomial chain's kernels run at priority 3, the witness MSMs' accumulations
-# at 0; B2's (G2) chain ends ~0.6 ms after the polynomial chain and the H accumulation starts when it does.  Variants (alt
-# builds of the library, keyless-zk-proofs_amd/build_alt.sh): the G2 accumulation at priority 2 / 3, the chain at 2 / 1.
+# Round 6: wave priorities inside a proof.  The witness MSMs' accumulations run at priority 0, their short kernels at 3, the
+# polynomial chain's kernels at K16_CHAIN_PRIO (3 until this experiment, 1 since); B2's (G2) chain ends ~0.6 ms after the
+# polynomial chain and the H accumulation starts when it does.  Variants = alt builds of the library, made first with
+#   cd keyless-zk-proofs_amd && for p in 0 2 3; do ./build_alt.sh chain$p "-DK16_CHAIN_PRIO=$p" ntt prover; done
+#   ./build_alt.sh g2prio3 "-DK16_G2_ACC_PRIO=3" msm_g2;  ./build_alt.sh g2prio2 "-DK16_G2_ACC_PRIO=2" msm_g2
+# (profiles/r06/ab_wave_priorities.log was taken when the default was still 3: its "default" row is today's chain3.)
 out=${1:-gpurun_out/r6_prio}
 mkdir -p "$out"
 P=keyless-zk-proofs_amd/alt
-variants=("" "g2prio3" "g2prio2" "chain2_g2prio3" "chain2" "chain1")
+variants=("" "chain3" "chain2" "chain0" "g2prio3" "g2prio2")
 for r in 1 2 3 4 5; do
   for v in "${variants[@]}"; do
     if [ -z "$v" ]; then L=keyless-zk-proofs_amd/libk16.so; else L=$P/libk16_$v.so; fi
