@@ -347,6 +347,8 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         dist.barrier()
     torch.cuda.synchronize()
     lat = []
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t_all = time.perf_counter()
     for i in range(proofs):
         t1 = time.perf_counter()
@@ -354,6 +356,10 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
         lat.append((time.perf_counter() - t1) * 1e3)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_all
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    # host CPU time one proof costs this PROCESS, all threads (witness scan on the library's pool, launches, the MSMs' host
+    # combines, blinding, JSON): what a node's host has to supply per proof and per GPU beside the GPU time
+    host_cpu_ms = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) * 1e3 / max(proofs, 1)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=XDEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -432,7 +438,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
                          "BASELINE.json's bound is HBM"}
         out = {"proofs_per_s": world * proofs / elapsed, "p50_ms": p50, "roofline": roof,
                "p99_ms": float(np.percentile(lat, 99)), "proofs": world * proofs, "entry": "k16_prover_prove_mem",
-               "n_vars": n_vars, "domain": N, "n_coefs": n_coefs, "n_public": 1,
+               "n_vars": n_vars, "domain": N, "n_coefs": n_coefs, "n_public": 1, "host_cpu_ms_per_proof": host_cpu_ms,
                "key": "synthetic, Keyless shape (the real zkey is not available offline); one resident copy per GPU",
                "parallelism": "replicas: one prover per GPU, no collective" if world > 1 else "single GPU",
                "setup_s": {"synthesize_key": t_key, "prover_create": t_create}, "checked": None,

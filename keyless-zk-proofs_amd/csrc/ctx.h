@@ -60,7 +60,7 @@ struct k16_tuning {
     // round 6 scheduling experiments (identical results): lane of the H MSM (default 1, behind C's MSM), lane of
     // the B1 MSM (default 0, behind A's), the H MSM's wait for the chain issued behind its sort's memset instead of in front
     int      g2_acc_split = 1; // lane pairs per segment in the witness MSMs' G2 accumulation (1, 2 or 4; msm_kernels.inc k_accumulate_split)
-    int      h_lane = 1, b1_lane = -1 /* unset: 0, or 3 on a shared GPU */, witness_seg = 0; // witness_seg: segment length of the witness MSMs' accumulations (default 32)
+    int      h_lane = 1, b1_lane = 0, witness_seg = 0; // witness_seg: segment length of the witness MSMs' accumulations (default 32)
     bool     h_wait_first = false;
     bool     trace = false, trace_enq = false, trace_host = false, verify_no_coop = false, verify_coop_trace = false;
     int      seg = 0, wsum_mlog = -1, witness_c = 0, ntt_tile_log = 0, narrow_chain = 0, narrow_chain_g2 = 0;
@@ -112,7 +112,6 @@ struct k16_ctx {
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
-    bool shared_gpu = false; // K16_OPT_SHARED_GPU: other provers' kernels share this GPU (throughput over latency)
     hipEvent_t wait_after_memset = nullptr; // one-shot: the next bucket sort waits for this event BEHIND its tables' memset
     void* pinned = nullptr;     // small pinned host staging buffer (coherent, mapped into the device's address space)
     void* pinned_dev = nullptr; // its device-side address: the last kernel of an MSM writes its <= 240 partial sums straight

@@ -80,7 +80,7 @@ k16_tuning k16_tuning::from_env()
     t.b2_first           = on("K16_B2_FIRST");
     t.no_acc_skip        = on("K16_NO_ACC_SKIP");
     t.h_lane             = std::max(1, std::min(k16_ctx::N_LANES - 1, num("K16_H_LANE", 1)));
-    t.b1_lane            = std::max(-1, std::min(k16_ctx::N_LANES - 1, num("K16_B1_LANE", -1)));
+    t.b1_lane            = std::max(0, std::min(k16_ctx::N_LANES - 1, num("K16_B1_LANE", 0)));
     t.h_wait_first       = onv("K16_H_WAIT_FIRST");
     t.g2_acc_split       = num("K16_G2_ACC_SPLIT", 1);
     t.witness_seg        = std::max(0, std::min(1024, num("K16_WITNESS_SEG", 0)));
@@ -272,10 +272,6 @@ extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
         // prover's bucket accumulation: +2.5-3 % proofs/s with two provers, +0-0.3 ms on a proof alone
         // (profiles/r04/ab_ntt_wg_per_cu.log)
         c->ntt_wg_per_cu = value ? std::min(3u, c->ntt_wg_per_cu_default) : c->ntt_wg_per_cu_default;
-        // ... and (round 6) the prover's B1 MSM gets a lane of its own instead of queueing behind A's on lane 0: equal latency
-        // for a proof alone, +2.5-5 % proofs/s with two provers on two boxes (profiles/r06/ab_h_msm_schedule_8queues_*.log,
-        // ab_witness_segment_length.log)
-        c->shared_gpu = value != 0;
         return K16_OK;
     default: return K16_ERR_ARG;
     }

@@ -1347,9 +1347,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
         const bool b_derived = p->b_derive && !b2_lead;
         // K16_B1_LANE (round 6 experiment): B1 on a lane of its own instead of behind A's MSM on lane 0 -- its accumulation then
         // starts with A's and C's (they all read lane 0's sort) and its tail runs under the chain, not after it
-        // Default: lane 0 for a proof alone, lane 3 when other provers share the GPU (K16_OPT_SHARED_GPU).
-        const int b1_want = ctx->tune.b1_lane >= 0 ? ctx->tune.b1_lane : (ctx->shared_gpu ? 3 : 0);
-        const int b1_lane = (b1_want == 3 && ctx->tune.h_lane != 3) ? 3 : 0;
+        const int b1_lane = (ctx->tune.b1_lane == 3 && ctx->tune.h_lane != 3) ? 3 : 0;
         if (b1_lane) K16_HIP(ctx, hipStreamWaitEvent(k16_lane_stream(ctx, b1_lane), p->ev_w, 0));
         ctx->cur_lane        = b1_lane;
         ctx->reuse_sort      = true;

@@ -129,3 +129,21 @@ def test_bench_strong_mode_two_ranks_through_the_c_exchange_over_the_double(fake
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ranks_seen"] == 2 and d["result_checked"] is True and d["scaling"] == "strong"
     assert "k16_rank_comm" in d["config"]["sharding"], d["config"]
+
+
+@pytest.mark.parametrize("async_mode", ["0", "1"])
+def test_bench_weak_mode_two_ranks_overlap_their_exchanges_through_the_c_leg(fake, async_mode):
+    """bench.py --gpus 2 in its DEFAULT (weak) mode: every rank owns a 2^16-point shard, each step's partial goes out with
+    k16_rank_comm_allgather_start while the next steps' MSMs run and comes back folded with _finish (up to four exchanges in
+    flight) -- the path the driver's scaling runs take at N > 1, here over the test double with both ranks on GPU 0.  The last
+    step's folded result equals the closed form over BOTH shards."""
+    env = dict(os.environ, K16_BENCH_SHARE_GPU="1", K16_BENCH_PREWARM="2", K16_RCCL_LIB=fake, K16_BENCH_NO_CONFIG_LEGS="1",
+               FAKE_RCCL_ASYNC=async_mode)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "K16_BENCH_EXCHANGE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--log2n", "16",
+                          "--proofs", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ranks_seen"] == 2 and d["result_checked"] is True and d["scaling"] == "weak"
+    assert "k16_rank_comm" in d["config"]["sharding"] and d["config"]["exchange_note"] is None, d["config"]
