@@ -15,8 +15,8 @@
 // Wave priority of the polynomial chain's kernels.  3 (above everything) until round 6; the witness MSMs' short kernels run at 3
 // too and their accumulations at 0.  With the chain at 1 it still wins against the accumulations it runs beside, but the
 // witness MSMs' fold / weighted-sum tails -- whose end, not the chain's, is what the H accumulation's start waits for -- are no
-// longer held up by NTT waves: p50 over 11 alternating runs on two boxes 5.35-5.57 (median 5.46) against 5.37-5.84 (5.67) ms,
-// two provers unchanged (profiles/r06/ab_wave_priorities.log, ab_chain_priority_second_box.log).  -DK16_CHAIN_PRIO=n to compare.
+// longer held up by NTT waves: p50 over 11 alternating runs on two boxes 5.35-5.57 (median 5.46) against 5.37-5.84 (5.67) ms, equal on
+// a third, two provers unchanged (profiles/r06/ab_wave_priorities.log, ab_chain_priority_second_box.log).  -DK16_CHAIN_PRIO=n to compare.
 #define K16_CHAIN_PRIO 1
 #endif
 using namespace k16;

@@ -229,6 +229,14 @@ class Context:
         arr = np.ascontiguousarray(arr)
         return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
 
+    def host_register(self, arr):
+        """page-lock a numpy array the caller keeps alive (k16_host_register): uploads from it are DMA copies"""
+        assert arr.flags["C_CONTIGUOUS"]
+        self._chk(self.L.k16_host_register(self.h, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+
+    def host_unregister(self, arr):
+        self._chk(self.L.k16_host_unregister(self.h, arr.ctypes.data_as(C.c_void_p)))
+
     def timer_start(self):
         self._chk(self.L.k16_timer_start(self.h))
 

@@ -91,6 +91,32 @@ def test_sharded_msm_2p22_closed_form_with_tables_made_on_the_shards():
         sm.close()
 
 
+def test_page_locked_scalars_give_the_same_msm(ctx):
+    """k16_host_register / k16_host_unregister (include/k16.h): the caller's scalar array page-locked for DMA uploads -- same
+    results through k16_msm_host and k16_msm_sharded_run as from pageable memory; a null pointer is an error code."""
+    import k16
+    n = (1 << 16) + 77
+    bases = ol.gen_points(0, 9, n)
+    scalars = np_scalars(404, n, "full256")
+    want = ol.msm(0, bases, scalars, nthreads=4)[1]
+    assert ctx.msm(0, bases, scalars)[1] == want
+    ctx.host_register(scalars)
+    try:
+        assert ctx.msm(0, bases, scalars)[1] == want
+        sm = k16.ShardedMsm(_devices(k16, 2), k16.G1, n)
+        try:
+            sm.set_bases(bases)
+            sm.set_piece_rows(4096, 0)
+            assert sm.run(scalars)[1] == want
+        finally:
+            sm.close()
+    finally:
+        ctx.host_unregister(scalars)
+    assert ctx.msm(0, bases, scalars)[1] == want             # pageable again
+    with pytest.raises(k16.K16Error):
+        ctx._chk(ctx.L.k16_host_register(ctx.h, None, 16))   # null pointer: K16_ERR_ARG
+
+
 def test_sharded_msm_error_paths():
     import k16
     L = k16.load()

@@ -23,7 +23,10 @@ with open(zpath, "wb") as f:
     f.write(bench.synth_zkey_bytes(ctx0, k16, n_vars, 1, N, n_coefs))
 r, s = bench._le32(12345678901234567890 % bench.R_MOD), bench._le32(98765432109876543210 % bench.R_MOD)
 wits = [bench.synth_witness(n_vars, 100 + i) for i in range(4)]
-provers = [k16.Prover(ctx0, zpath)] + [k16.Prover(k16.Context(0), zpath) for _ in range(P - 1)]
+# round 6: the other provers share the first one's resident key (k16_prover_create_shared), as FullProver's K16_DEVICES=0,0 does
+p0 = k16.Prover(ctx0, zpath)
+share = None if os.environ.get("K16_SOAK_NO_SHARE") else p0
+provers = [p0] + [k16.Prover(k16.Context(0), zpath, share_key_of=share) for _ in range(P - 1)]
 ref = [provers[0].prove_mem(w, r, s) for w in wits]
 bad = []
 
