@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--provers", type=int, default=3)
     ap.add_argument("--wave", type=int, default=64)
-    ap.add_argument("--witnesses", type=int, default=8)
+    ap.add_argument("--witnesses", type=int, default=64)
     ap.add_argument("--scale", type=float, default=1.0)
     args = ap.parse_args()
     ctx = k16.Context(0)
@@ -37,9 +37,10 @@ def main():
     zpath = "/tmp/k16_config4_%d.zkey" % os.getpid()
     open(zpath, "wb").write(key["zkey"])
     t_key = time.time() - t0
-    wits = [key["new_witness"](100 + i) for i in range(args.witnesses)]
+    wits = [vkb.fast_witness(key["shape"], 100 + i) for i in range(args.witnesses)]
     ctxs = [ctx] + [k16.Context(0) for _ in range(args.provers - 1)]
-    provers = [k16.Prover(c, zpath) for c in ctxs]
+    provers = [k16.Prover(ctx, zpath)]
+    provers += [k16.Prover(c, zpath, share_key_of=provers[0]) for c in ctxs[1:]]     # one resident key (round 6)
     V = k16.VerifyingKey(ctx, key["vk"])
     for pv in provers:
         pv.prove_mem(wits[0][0])

@@ -48,7 +48,7 @@ def main():
     w_kb = write.get(k, (0.0, 0))[0]
     res = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (one counter per pass), "
-                  "K16_BENCH_DEPTH=1 bench.py --steps 3 --warmup 1 --proofs 0; per-kernel averages in profiles/r05/pmc_*_per_kernel.txt (tools/pmc_kernel.py on the same passes)",
+                  "K16_BENCH_DEPTH=1 bench.py --steps 3 --warmup 1 --proofs 0; per-kernel averages in profiles/r06/pmc_*_per_kernel.txt (tools/pmc_kernel.py on the same passes)",
         "kernel": k[:60],
         "commit": commit,
         "kernel_sources_sha16": digest,
