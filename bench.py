@@ -395,22 +395,37 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
                 provers[i].prove_mem(wits[(i + k) % len(wits)])
                 lats[i].append((time.perf_counter() - t1) * 1e3)
 
-        if dist is not None:
-            dist.barrier()
-        t_all = time.perf_counter()
-        th = [threading.Thread(target=worker, args=(i,)) for i in range(n_conc)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        el = time.perf_counter() - t_all
-        allv = [x for l in lats for x in l]
-        if dist is not None:
-            t = torch.tensor([el], dtype=torch.float64, device=XDEV)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        thr = {"provers_per_gpu": n_conc, "proofs_per_s": world * n_conc * thr_proofs / el, "p50_ms": float(np.median(allv)),
-               "p99_ms": float(np.percentile(allv, 99)), "proofs": world * n_conc * thr_proofs}
+        def timed_wave():
+            for l in lats:
+                del l[:]
+            if dist is not None:
+                dist.barrier()
+            r0 = resource.getrusage(resource.RUSAGE_SELF)
+            t_all = time.perf_counter()
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(n_conc)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            el = time.perf_counter() - t_all
+            r1 = resource.getrusage(resource.RUSAGE_SELF)
+            cpu_ms = ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / (n_conc * thr_proofs)
+            allv = [x for l in lats for x in l]
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device=XDEV)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            return {"provers_per_gpu": n_conc, "proofs_per_s": world * n_conc * thr_proofs / el, "p50_ms": float(np.median(allv)),
+                    "p99_ms": float(np.percentile(allv, 99)), "proofs": world * n_conc * thr_proofs, "host_cpu_ms_per_proof": cpu_ms}
+
+        thr = timed_wave()
+        # the same wave with K16_OPT_YIELDING_WAITS (what FullProver sets for a pool): the callers' waits poll + sleep instead of
+        # spinning inside the runtime -- same rate, a fraction of the host CPU time per proof (a node runs 16 such callers)
+        for c in [ctx] + others:
+            c.set_option(k16.OPT_YIELDING_WAITS, 1)
+        thr["yielding_waits"] = timed_wave()
+        for c in [ctx] + others:
+            c.set_option(k16.OPT_YIELDING_WAITS, 0)
         for pv in provers[1:]:
             pv.close()
         for c in others:
@@ -474,6 +489,22 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
                                        "note": "witness already in the prover's pinned upload buffers in compact form when the call starts"}
         except Exception as e:
             out["compact_hand_off"] = {"error": repr(e)}
+        try:
+            # one proof at a time with K16_OPT_YIELDING_WAITS: what the waits' sleeps cost a proof's latency, and save its host
+            ctx.set_option(k16.OPT_YIELDING_WAITS, 1)
+            ylat = []
+            r0 = resource.getrusage(resource.RUSAGE_SELF)
+            for i in range(proofs):
+                t1 = time.perf_counter()
+                prover.prove_mem(wits[i % len(wits)])
+                ylat.append((time.perf_counter() - t1) * 1e3)
+            r1 = resource.getrusage(resource.RUSAGE_SELF)
+            out["yielding_waits"] = {"p50_ms": float(np.median(ylat)), "p99_ms": float(np.percentile(ylat, 99)),
+                                     "host_cpu_ms_per_proof": ((r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)) * 1e3 / max(proofs, 1)}
+        except Exception as e:
+            out["yielding_waits"] = {"error": repr(e)}
+        finally:
+            ctx.set_option(k16.OPT_YIELDING_WAITS, 0)
         if world == 1:
             try:
                 out["facade"] = facade_leg(zpath, wpath, max(4, proofs // 2))

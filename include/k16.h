@@ -108,8 +108,12 @@ const char* k16_last_error(const k16_ctx* ctx);
  * K16_OPT_SHARED_GPU (0/1, default 0): other contexts prove on the same GPU at the same time (FullProver sets it for the
  * entries of K16_DEVICES that name a device more than once): kernels leave room for the other provers' (the NTT passes
  * keep three workgroups per CU instead of four) -- more proofs per second, up to 0.3 ms more for a proof alone.  Results
- * are identical either way. */
-enum { K16_OPT_PIPELINED_MSM = 1, K16_OPT_GRAPHS = 2, K16_OPT_SHARED_GPU = 3 };
+ * are identical either way.
+ * K16_OPT_YIELDING_WAITS (0/1, default 0; round 6): the host waits of k16_msm_finish* and of the prove calls poll the device
+ * (hipEventQuery) with short sleeps instead of spinning inside the runtime: a caller that waits for its proof costs next to no CPU
+ * (a proof otherwise keeps one core busy for its whole 5 ms) at up to ~50 us per wait -- for hosts that run many provers (FullProver
+ * sets it for every pool with more than one prover).  Results are identical either way. */
+enum { K16_OPT_PIPELINED_MSM = 1, K16_OPT_GRAPHS = 2, K16_OPT_SHARED_GPU = 3, K16_OPT_YIELDING_WAITS = 4 };
 int         k16_ctx_set_option(k16_ctx* ctx, int option, int value);
 int         k16_sync(k16_ctx* ctx);
 /* the HIP stream every kernel of this context is launched on (hipStream_t as void*) */

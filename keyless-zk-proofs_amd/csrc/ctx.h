@@ -112,6 +112,7 @@ struct k16_ctx {
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
+    bool yielding_waits = false; // K16_OPT_YIELDING_WAITS: host waits poll + sleep instead of spinning inside the runtime (k16_event_wait)
     hipEvent_t wait_after_memset = nullptr; // one-shot: the next bucket sort waits for this event BEHIND its tables' memset
     void* pinned = nullptr;     // small pinned host staging buffer (coherent, mapped into the device's address space)
     void* pinned_dev = nullptr; // its device-side address: the last kernel of an MSM writes its <= 240 partial sums straight
@@ -241,6 +242,9 @@ k16_host_pool* k16_ctx_pool(k16_ctx* ctx);
 // 0-2 plus its chain stream, the MSM benchmark lanes 0-3 (measured: with an idle fifth stream a proof took 8.7 instead
 // of 7.7 ms).
 hipStream_t k16_lane_stream(k16_ctx* ctx, int lane);
+// wait for an event on the host: hipEventSynchronize (the runtime spins: lowest latency, one busy core per waiting caller), or --
+// K16_OPT_YIELDING_WAITS -- hipEventQuery + short sleeps (a waiting caller costs next to no CPU; up to ~50 us later)
+hipError_t k16_event_wait(k16_ctx* ctx, hipEvent_t ev);
 
 #define K16_HIP(ctx, call)                                                                         \
     do {                                                                                           \

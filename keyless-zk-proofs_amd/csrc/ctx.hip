@@ -5,6 +5,8 @@
 #include <sched.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <thread>
 #include "ctx.h"
 #include "bn254_fq2pair.h"
 #include "bn254_fq9.h"
@@ -244,6 +246,19 @@ hipStream_t k16_lane_stream(k16_ctx* ctx, int lane)
     return L.stream;
 }
 
+hipError_t k16_event_wait(k16_ctx* ctx, hipEvent_t ev)
+{
+    if (!ctx->yielding_waits) return hipEventSynchronize(ev);
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q != hipErrorNotReady) return q;
+        if (spins < 8)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(spins < 64 ? 20 : 50));
+    }
+}
+
 extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
 {
     return k16_guard(c, [&]() -> int {
@@ -272,6 +287,9 @@ extern "C" int k16_ctx_set_option(k16_ctx* c, int option, int value)
         // prover's bucket accumulation: +2.5-3 % proofs/s with two provers, +0-0.3 ms on a proof alone
         // (profiles/r04/ab_ntt_wg_per_cu.log)
         c->ntt_wg_per_cu = value ? std::min(3u, c->ntt_wg_per_cu_default) : c->ntt_wg_per_cu_default;
+        return K16_OK;
+    case K16_OPT_YIELDING_WAITS:
+        c->yielding_waits = value != 0;
         return K16_OK;
     default: return K16_ERR_ARG;
     }

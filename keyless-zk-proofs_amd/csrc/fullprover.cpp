@@ -127,6 +127,7 @@ public:
                 int sharing = 0;
                 for (auto& o : slots) sharing += o.device == s->device;
                 if (sharing > 1) (void)k16_ctx_set_option(s->ctx, K16_OPT_SHARED_GPU, 1);
+                if (slots.size() > 1) (void)k16_ctx_set_option(s->ctx, K16_OPT_YIELDING_WAITS, 1);
             }
         } catch (...) {
             ok = false;
@@ -230,6 +231,8 @@ FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullPro
             int sharing = 0;
             for (auto& o : p->slots) sharing += o.device == s.device;
             if (sharing > 1) (void)k16_ctx_set_option(s.ctx, K16_OPT_SHARED_GPU, 1);
+            // a pool means several callers waiting for proofs at once: their waits sleep instead of spinning (include/k16.h)
+            if (p->slots.size() > 1) (void)k16_ctx_set_option(s.ctx, K16_OPT_YIELDING_WAITS, 1);
         }
     } catch (...) {
         delete p;

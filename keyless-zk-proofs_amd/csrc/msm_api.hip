@@ -464,7 +464,7 @@ static int msm_finish_any(k16_ctx* ctx, int expect_group, void* h_out_xyzz, void
     {
         HostTimer hw(ctx, "host_finish_wait");
         hipError_t e = hipSetDevice(ctx->device);
-        if (e == hipSuccess) e = hipEventSynchronize(ctx->pend_ev[pd.slot]); // only this MSM's results; later ones keep running
+        if (e == hipSuccess) e = k16_event_wait(ctx, ctx->pend_ev[pd.slot]); // only this MSM's results; later ones keep running
         if (e != hipSuccess) {
             pop(); // the entry is consumed either way: a failed MSM must not be handed to the next caller
             ctx->err = std::string("k16_msm_finish: ") + hipGetErrorString(e);

@@ -1463,7 +1463,7 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
     ht("H finished");
     K16_HIP(ctx, hipStreamWaitEvent(st, ctx->pend_ev[(ctx->pend_head + k16_ctx::PEND_SLOTS - 1) % k16_ctx::PEND_SLOTS], 0));
     K16_HIP(ctx, hipEventRecord(ctx->ev_b, st));
-    K16_HIP(ctx, hipEventSynchronize(ctx->ev_b));
+    K16_HIP(ctx, k16_event_wait(ctx, ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
     if (packed_upload && *p->packer->h_bad) { // (every MSM of this proof has been consumed: nothing is left behind)
         ctx->err = (*p->packer->h_bad & 1u) ? "compact witness: wire number out of range in the wide-value list"

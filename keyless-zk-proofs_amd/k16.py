@@ -15,6 +15,7 @@ G1, G2 = 0, 1
 OPT_PIPELINED_MSM = 1
 OPT_GRAPHS = 2
 OPT_SHARED_GPU = 3
+OPT_YIELDING_WAITS = 4
 FQ, FR = 0, 1
 FQ9, FR9, FQ2N, FQ2H = 2, 3, 4, 5          # the same ops on the hot kernels' radix-2^29 representations (include/k16.h)
 G1_ENG9, G2_ENG2N, G2_PAIR = 2, 3, 4

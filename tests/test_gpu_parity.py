@@ -1120,6 +1120,41 @@ def test_compact_witness_hand_off(tmp_path):
         c.close()
 
 
+def test_yielding_waits_give_the_same_results(tmp_path, toy_paths):
+    """K16_OPT_YIELDING_WAITS (include/k16.h, round 6): the host waits of k16_msm_finish* and of the prove calls poll + sleep
+    instead of spinning inside the runtime -- a scheduling choice of the HOST: MSM results and proof bytes equal the oracle's
+    (RS/multiexp.cpp:183-245, RS/groth16.cpp:41-360) with it on, off again, and with four MSMs in flight."""
+    import k16
+    zkey, wtns, _ = toy_paths
+    c = k16.Context(0)
+    try:
+        n = 5000
+        bases = ol.gen_points(0, 2, n)
+        scalars = np_scalars(515, n, "full256")
+        want = ol.msm(0, bases, scalars, nthreads=4)[1]
+        p = k16.Prover(c, zkey)
+        z = bytes(32)
+        proof = ol.prove_files(zkey, wtns, z, z)
+        for on in (1, 0, 1):
+            c.set_option(k16.OPT_YIELDING_WAITS, on)
+            assert c.msm(0, bases, scalars)[1] == want
+            assert p.prove_file(wtns, z, z) == proof
+            d_b, d_s = c.to_device(bases), c.to_device(scalars)
+            for lane in range(4):
+                c.set_lane(lane)
+                c.msm_enqueue(k16.G1, d_b, d_s, n)
+            c.set_lane(0)
+            for _ in range(4):
+                assert c.msm_finish(k16.G1)[1] == want
+            d_b.free()
+            d_s.free()
+        with pytest.raises(k16.K16Error):
+            c.set_option(99, 1)
+        p.close()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("field,sel", [(0, "FQ9"), (1, "FR9")])
 def test_lazy_limb_butterfly_forms(ctx, field, sel):
     """fadd9_lazy / fsub9_lazy4_t (bn254_fq9.h): the NTT double stage keeps the sums and differences of its first stage
