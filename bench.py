@@ -804,7 +804,10 @@ def config4_wave_leg(k16, torch, dist, rank, world, dev, wave, scale):
                    "p50_ms": float(np.median(lat)), "p99_ms": float(np.percentile(lat, 99)),
                    "verify_wave_ms": t_verify * 1e3, "all_accepted": bool(all(ok)), "wrong_inputs_rejected": not any(wrong),
                    "distinct": bool(distinct), "proofs_per_s_proved_and_verified": wave / (elapsed + t_verify),
-                   "setup_s": {"build_valid_key": t_key, "witnesses": t_wit}}
+                   "setup_s": {"build_valid_key": t_key, "witnesses": t_wit},
+                   "note": "a different key from the `proof` leg's: valid (its proofs verify), 3.7 M coefficients, and every bit wire has "
+                           "non-zero B1 / B2 points (the proof leg's synthetic key has half of those rows (0,0)), so the B2 MSM is twice "
+                           "the work and a proof ~0.8 ms longer; 64 distinct 43 MB witnesses, none of them cache-warm"}
             if two is not None:
                 js2 = two.pop("_proofs")
                 pr2 = [gio.proof_from_json(js2[j]) for j in order]
