@@ -124,7 +124,8 @@ int k16_dev_alloc(k16_ctx* ctx, size_t bytes, void** dptr);
 int k16_dev_free(k16_ctx* ctx, void* dptr);
 int k16_h2d(k16_ctx* ctx, void* dptr, const void* hptr, size_t bytes);
 int k16_d2h(k16_ctx* ctx, void* hptr, const void* dptr, size_t bytes);
-/* Page-lock a host buffer the caller owns (hipHostRegister), so that k16_h2d / k16_msm_host / k16_msm_sharded_run copy from
+/* Page-lock a host buffer the caller owns (hipHostRegister) -- e.g. the scalar array Curve::multiMulByScalar (curve.hpp:209-215)
+ * receives by pointer on every call -- so that k16_h2d / k16_msm_host / k16_msm_sharded_run copy from
  * it by DMA instead of through the runtime's staging buffer (a 2^24-row scalar array: 24 instead of 27 ms per upload, and
  * the copy no longer occupies a host core).  The buffer must stay mapped until k16_host_unregister.  Not needed for
  * correctness anywhere. */
@@ -309,7 +310,7 @@ int k16_point_op_vec(k16_ctx* ctx, int group, int op, const void* h_p1, const vo
 int  k16_prover_create(k16_ctx* ctx, const char* zkey_path, k16_prover** out);
 int  k16_prover_create_mem(k16_ctx* ctx, const void* zkey_bytes, size_t zkey_size, k16_prover** out);
 /* A further prover of the SAME key on the SAME device as `other` (throughput mode: several provers sharing one GPU, what
- * FullProver builds for K16_DEVICES=0,0): it shares other's read-only device data -- point tables, H window tables,
+ * FullProver builds for K16_DEVICES=0,0; replaces the per-instance zkey mapping + section walk of fullprover.cpp:136-181): it shares other's read-only device data -- point tables, H window tables,
  * coefficients, masks, 2.7 GB at the Keyless shape -- by reference count instead of parsing, uploading and preparing the key
  * again (0.1 s instead of 1.1 s), and owns only what a proof writes.  ctx must be a context of its own on that device.  The
  * shared part is freed with the last prover that uses it; `other` may be destroyed first.  Same proofs as a prover made by
