@@ -339,9 +339,9 @@ int  k16_prover_prove_mem(k16_prover* p, const void* h_wtns, uint64_t n_vars, co
  *   k16_prover_prove_compact     proves the witness the buffers hold, n_wide entries of the list being valid: the proof's
  *                                first kernel starts at once.  Same result, outputs and errors as k16_prover_prove_mem for
  *                                the same witness; K16_ERR_ARG when n_wide exceeds the list (such a witness goes through
- *                                k16_prover_prove_mem), K16_ERR_FORMAT for a wire number out of range or a listed wire whose
- *                                narrow byte is not 0 (checked on the device by the kernel that reads the list: the entry is
- *                                skipped, the call fails when its device work has been joined).
+ *                                k16_prover_prove_mem), K16_ERR_FORMAT for a wire number out of range, a listed wire whose
+ *                                narrow byte is not 0, or a wire listed twice (checked on the device by the kernel that reads
+ *                                the list: the entry is skipped, the call fails when its device work has been joined).
  * One proof at a time per prover, as for every prove call; k16_prover_prove_mem / _prove_file overwrite the same buffers. */
 int  k16_prover_compact_buffers(k16_prover* p, uint8_t** narrow, uint32_t** wide_idx, uint8_t** wide_val, uint64_t* wide_cap);
 int  k16_prover_prove_compact(k16_prover* p, uint64_t n_wide, const uint8_t* r_std, const uint8_t* s_std, char* out_json,

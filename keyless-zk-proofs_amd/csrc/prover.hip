@@ -281,14 +281,22 @@ __global__ void __launch_bounds__(256) k_wtns_expand_wide(WideLists L, Fr* __res
     if (t >= L.n_lists) return;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < L.count[t]; j += gridDim.x * blockDim.x) {
         const uint32_t i = L.idx[t][j];
-        if (i >= L.n_vars || n16[i] != 0) {
-            *(volatile uint32_t*)L.bad = i >= L.n_vars ? 1u : 2u; // (a plain store: no PCIe atomic needed; any bad entry's code will do)
+        if (i >= L.n_vars) {
+            *(volatile uint32_t*)L.bad = 1u; // (a plain store: no PCIe atomic needed; any bad entry's code will do)
+            continue;
+        }
+        // claim the wire: bit 15 of its 16-bit entry, set atomically on the aligned word that holds it -- what was there before
+        // says whether the wire had a byte of its own (code 2) or was listed already (code 4: a duplicate entry, round 6;
+        // without the atomic two lanes could both find the entry free and the value that survives would depend on their order)
+        const uint32_t sh  = (i & 1u) * 16u;
+        const uint32_t old = (atomicOr(reinterpret_cast<uint32_t*>(n16) + (i >> 1), 0x8000u << sh) >> sh) & 0xffffu;
+        if (old != 0) {
+            *(volatile uint32_t*)L.bad = (old & 0x8000u) ? 4u : 2u;
             continue;
         }
         uint4*         d = reinterpret_cast<uint4*>(&out[i]);
         d[0]     = L.val[t][2 * j];
         d[1]     = L.val[t][2 * j + 1];
-        n16[i]   = (uint16_t)0x8000u;
     }
 }
 
@@ -1466,8 +1474,10 @@ static int prove_mem_inner(k16_prover* p, const void* h_wtns, uint64_t n_vars, i
     K16_HIP(ctx, k16_event_wait(ctx, ctx->ev_b));
     if (device_ms) K16_HIP(ctx, hipEventElapsedTime(device_ms, ctx->ev_a, ctx->ev_b));
     if (packed_upload && *p->packer->h_bad) { // (every MSM of this proof has been consumed: nothing is left behind)
-        ctx->err = (*p->packer->h_bad & 1u) ? "compact witness: wire number out of range in the wide-value list"
-                                            : "compact witness: a listed wire must have a zero byte in the narrow array";
+        const uint32_t code = *p->packer->h_bad;
+        ctx->err = (code & 1u)   ? "compact witness: wire number out of range in the wide-value list"
+                   : (code & 4u) ? "compact witness: a wire is listed twice in the wide-value list"
+                                 : "compact witness: a listed wire must have a zero byte in the narrow array";
         return K16_ERR_FORMAT;
     }
     pi_c = h_add(pi_c, pih);

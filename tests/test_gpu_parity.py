@@ -1089,6 +1089,12 @@ def test_compact_witness_hand_off(tmp_path):
         with pytest.raises(k16.K16Error) as e:
             p.prove_compact(n_wide, r, s)
         assert e.value.rc == -5
+        n_wide = _fill_compact(p, w)
+        idx[n_wide] = idx[7]                             # a wire listed twice (round 6: claimed atomically on the device)
+        val[n_wide] = val[7]
+        with pytest.raises(k16.K16Error) as e:
+            p.prove_compact(n_wide + 1, r, s)
+        assert e.value.rc == -5 and "twice" in str(e.value)
         with pytest.raises(k16.K16Error) as e:
             p.prove_compact(len(idx) + 1, r, s)          # more than the list holds
         assert e.value.rc == -3
