@@ -653,6 +653,16 @@ def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
 
         sm.run(scalars)                                   # warm-up: the lanes' workspaces
         res_host, host = timed(lambda: sm.run(scalars)[0], 3)
+        # ... the same host array page-locked by the caller (k16_host_register): the uploads are then DMA copies
+        pinned_t, res_pin = None, None
+        try:
+            sm.shard_ctx(0).host_register(scalars)
+            try:
+                res_pin, pinned_t = timed(lambda: sm.run(scalars)[0], 3)
+            finally:
+                sm.shard_ctx(0).host_unregister(scalars)
+        except Exception as e:
+            pinned_t = {"error": repr(e)}
         ds = []
         for r in range(sm.count()):
             slo, shi = sm.shard_range(r)
@@ -683,6 +693,10 @@ def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
                    "ranks_seen": ranks_seen, "shards": sm.count() * ranks_seen, "devices": devices if world == 1 else "one per rank",
                    "host_scalars": dict(host, points_per_s=total / (host["total_ms"] * 1e-3),
                                         note="scalars handed over in pageable host memory inside every run (PCIe-inclusive)"),
+                   "host_scalars_page_locked": (dict(pinned_t, points_per_s=total / (pinned_t["total_ms"] * 1e-3),
+                                                     same_result=bool(k16.points_sum(k16.G1, np.frombuffer(res_pin, dtype=np.uint8).reshape(1, 128))[1] == want),
+                                                     note="the same array after k16_host_register (the caller's one-time cost, outside the run)")
+                                                if pinned_t and "total_ms" in pinned_t else pinned_t),
                    "device_scalars": dict(devt, points_per_s=total / (devt["total_ms"] * 1e-3)),
                    "result_checked": all(ok), "exchange_note": note,
                    "setup_s": {"scalars": t_scal, "bases_on_device": t_bases, "closed_form_on_host": t_check}}
