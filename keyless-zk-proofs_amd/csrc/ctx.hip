@@ -5,6 +5,7 @@
 #include <sched.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include "ctx.h"
@@ -112,6 +113,19 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     k16_ctx* c = new k16_ctx();
     c->device  = device;
     c->tune    = k16_tuning::from_env(); // the only place the library reads its tuning switches
+    // K16_STREAM_SKEW=a[,b] (round 6 experiment): the n-th context of the process creates (a * n + b) mod 8 placeholder
+    // streams before its own, which shifts the hardware queues (and so the dispatch pipes) its streams land on relative to the
+    // other contexts' -- which streams of two provers sharing a GPU take turns on one pipe
+    if (const char* e = getenv("K16_STREAM_SKEW")) {
+        static std::atomic<int> n_ctx{0};
+        // "a" or "a,b": context n gets (a * n + b) mod 8 placeholders
+        const char* comma = strchr(e, ',');
+        const int   skew  = (n_ctx.fetch_add(1) * atoi(e) + (comma ? atoi(comma + 1) : 0)) & 7;
+        for (int k = 0; k < skew; k++) {
+            hipStream_t dummy = nullptr;
+            (void)hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking); // (kept for the life of the process)
+        }
+    }
     bool lanes_ok = true;
     for (int i = 0; i < k16_ctx::N_LANES; i++)
         lanes_ok = lanes_ok && (i > 0 || hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) == hipSuccess) &&
