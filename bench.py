@@ -590,6 +590,16 @@ def make_rank_exchange(dist, ctx, sharding):
     return ex, note
 
 
+def all_ranks_ok(torch, dist, ok):
+    """Agreement before a leg's first collective: a rank whose LOCAL set-up failed (allocation, key load ...) must not leave the
+    others waiting inside a collective it will never join -- every rank learns of it here and the leg is skipped everywhere."""
+    if dist is None:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], device=XDEV)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
 def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
     """BASELINE config 5: ONE G1 MSM of 2^log2n points (default 2^26: 4 GiB of points, 2 GiB of scalars) cut N ways.
     N = 1: k16_msm_sharded_* with EIGHT shards over the visible devices (eight contexts on device 0 on a one-GPU box), host-side
@@ -601,17 +611,17 @@ def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
     total = 1 << log2n
     lo, hi = sharding.shard_range(total, world, rank)
     n = hi - lo
-    t0 = time.time()
-    scalars = fast_scalars(n, seed=0x2626 + rank)
-    t_scal = time.time() - t0
     if world == 1:
         ndev = max(1, k16.load().k16_device_count())
         devices = [r % ndev for r in range(8)]
     else:
         devices = [dev]
-    sm = k16.ShardedMsm(devices, k16.G1, n)
-    ex, note = None, None
-    try:
+    sm, ex, note, setup_err = None, None, None, None
+    try:                                                   # local set-up: no collective in here
+        t0 = time.time()
+        scalars = fast_scalars(n, seed=0x2626 + rank)
+        t_scal = time.time() - t0
+        sm = k16.ShardedMsm(devices, k16.G1, n)
         t0 = time.time()
         for r in range(sm.count()):
             slo, shi = sm.shard_range(r)
@@ -619,6 +629,13 @@ def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
             sm.set_bases_device(r, d)
             d.free()
         t_bases = time.time() - t0
+    except Exception as e:
+        setup_err = repr(e)
+    if not all_ranks_ok(torch, dist, setup_err is None):
+        if sm is not None:
+            sm.close()
+        return {"error": "set-up failed on a rank (%s): leg skipped on all ranks" % (setup_err or "another rank")} if rank == 0 else None
+    try:
         ex, note = make_rank_exchange(dist, sm.shard_ctx(0), sharding)
 
         def fold(xyzz):
@@ -700,8 +717,9 @@ def strong_leg(k16, torch, dist, sharding, rank, world, dev, log2n):
                    "device_scalars": dict(devt, points_per_s=total / (devt["total_ms"] * 1e-3)),
                    "result_checked": all(ok), "exchange_note": note,
                    "setup_s": {"scalars": t_scal, "bases_on_device": t_bases, "closed_form_on_host": t_check}}
-            if not all(ok) and not os.environ.get("K16_BENCH_NOCHECK"):
-                raise SystemExit("bench.py: the sharded 2^%d MSM differs from the closed form" % log2n)
+            if not all(ok):      # a SECONDARY leg: say so loudly, keep the line (the headline's own check still ends the run)
+                out["error"] = "the sharded 2^%d MSM differs from the closed form" % log2n
+                print("bench.py: ERROR: " + out["error"], file=sys.stderr, flush=True)
         return out
     finally:
         if ex is not None:
@@ -722,26 +740,38 @@ def config4_wave_leg(k16, torch, dist, rank, world, dev, wave, scale):
     meta = [None]
     t0 = time.time()
     if rank == 0:
-        key = vkb.build(lambda g, sc: ctx.synth_points_scalars(g, sc), max(int(1209229 * scale), 64), max(int(107487 * scale), 8),
-                        max(int(26870 * scale), 8), seed=11)
-        with open(zpath + ".part", "wb") as f:
-            f.write(key["zkey"])
-        os.replace(zpath + ".part", zpath)
-        meta = [{k: key[k] for k in ("shape", "vk", "n_vars", "domain", "n_coefs")}]
-        del key
+        try:                                          # (a failure here travels in the broadcast: nobody is left waiting)
+            key = vkb.build(lambda g, sc: ctx.synth_points_scalars(g, sc), max(int(1209229 * scale), 64), max(int(107487 * scale), 8),
+                            max(int(26870 * scale), 8), seed=11)
+            with open(zpath + ".part", "wb") as f:
+                f.write(key["zkey"])
+            os.replace(zpath + ".part", zpath)
+            meta = [{k: key[k] for k in ("shape", "vk", "n_vars", "domain", "n_coefs")}]
+            del key
+        except Exception as e:
+            meta = [{"error": repr(e)}]
     if dist is not None:
         dist.broadcast_object_list(meta, src=0)
     meta = meta[0]
+    if "error" in meta:
+        ctx.close()
+        return {"error": "the valid key could not be built: %s" % meta["error"]} if rank == 0 else None
     t_key = time.time() - t0
     prover, others, V = None, [], None
     try:
-        prover = k16.Prover(ctx, zpath)
-        mine = [j for j in range(wave) if j % world == rank]
-        t0 = time.time()
-        wits = {j: vkb.fast_witness(meta["shape"], 5000 + j) for j in mine}
-        t_wit = time.time() - t0
-        for j in mine[:2]:
-            prover.prove_mem(wits[j][0])              # warm-up (the clocks; the workspaces exist since create)
+        setup_err = None
+        try:                                          # local set-up: no collective in here
+            prover = k16.Prover(ctx, zpath)
+            mine = [j for j in range(wave) if j % world == rank]
+            t0 = time.time()
+            wits = {j: vkb.fast_witness(meta["shape"], 5000 + j) for j in mine}
+            t_wit = time.time() - t0
+            for j in mine[:2]:
+                prover.prove_mem(wits[j][0])          # warm-up (the clocks; the workspaces exist since create)
+        except Exception as e:
+            setup_err = repr(e)
+        if not all_ranks_ok(torch, dist, setup_err is None):
+            return {"error": "set-up failed on a rank (%s): leg skipped on all ranks" % (setup_err or "another rank")} if rank == 0 else None
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -828,9 +858,11 @@ def config4_wave_leg(k16, torch, dist, rank, world, dev, wave, scale):
                 two["all_accepted"] = bool(all(V.verify_batch(pr2, ins)))
                 out["two_provers_one_gpu"] = two
                 if not two["all_accepted"]:
-                    raise SystemExit("bench.py: a proof of the two-prover wave was rejected")
+                    out["error"] = "a proof of the two-prover wave was rejected"
             if not (all(ok) and not any(wrong) and distinct):
-                raise SystemExit("bench.py: config 4 wave: a proof was rejected (or accepted with a foreign input)")
+                out["error"] = "config 4 wave: a proof was rejected (or accepted with a foreign input)"
+            if "error" in out:   # a SECONDARY leg: say so loudly, keep the line
+                print("bench.py: ERROR: " + out["error"], file=sys.stderr, flush=True)
         return out
     finally:
         if V is not None:
