@@ -22,6 +22,11 @@ The same JSON line also carries
   proof         BASELINE config 3 / 4: full Groth16 proofs of a synthetic Keyless-shape key (nVars 1,343,588, N = 2^21,
                 8.3 M coefficients) on every rank (one prover per GPU, replicas): proofs/s over all ranks, p50 / p99
                 latency through k16_prover_prove_mem, and (world size 1) through the file-based C++ FullProver facade
+  config4_wave  BASELINE config 4 (round 6): a wave of 64 DISTINCT witnesses of a VALID synthetic Keyless-shape key, proof j on
+                rank j mod N, then ONE k16_verify_batch of all 64 on rank 0
+  strong_2p26   BASELINE config 5 (round 6): ONE 2^26-point G1 MSM -- eight shards through k16_msm_sharded_* at N = 1, one shard per
+                rank + libk16.so's k16_rank_comm_* (ONE ncclAllGather) at N > 1 -- closed form checked
+                (both after the timed region; K16_BENCH_NO_CONFIG_LEGS=1 skips them)
   roofline      for the dominant kernel (bucket accumulation): algorithmic bytes / measured launch time
   cpu_baseline  the CPU oracle (oracle/, a port of the reference algorithm) timed on this host on the same MSM workload
                 and on ONE full proof of the same key, which is also the check of the GPU proof (rank 0, N = 1 only)
@@ -1116,12 +1121,7 @@ def main():
 
     pending_x = []   # the previous step's exchange, still in flight
 
-    # strong mode (BASELINE config 5: ONE MSM sharded over the ranks) exchanges through the library's own C entry points
-    # (k16_rank_comm_*: ncclAllGather issued by libk16.so, sharding.RankExchange) -- the path a C++ service has; the weak
-    # mode's per-step exchange stays on torch.distributed's asynchronous all_gather, which it overlaps with the next step.
-    # K16_BENCH_EXCHANGE=c|torch overrides; a C leg that cannot start (no RCCL library) falls back and says so.
-    c_exchange, c_exchange_note = None, None
-    # Round 6: the library's own RCCL leg (k16_rank_comm_*: ncclAllGather issued by libk16.so) is the default carrier in BOTH
+    # The library's own RCCL leg (k16_rank_comm_*: ncclAllGather issued by libk16.so, sharding.RankExchange) is the carrier in BOTH
     # modes -- what SCALE measures is then the path a C++ service has.  Weak mode keeps its overlap: k16_rank_comm_allgather_start
     # enqueues step k's exchange, _finish completes step k - 1's.  K16_BENCH_EXCHANGE=torch selects torch.distributed's
     # all_gather; a C leg that cannot start on every rank falls back to it LOUDLY (stderr + `exchange_note`).  On the one-GPU
