@@ -286,6 +286,28 @@ def facade_leg(zpath, wpath, proofs, mem=False):
                     "the reference's own metric (RS/fullprover.cpp:226-244, whole milliseconds)"}
 
 
+def facade_pool_leg(zpath, wpath, proofs_per_thread):
+    """Throughput mode THROUGH THE DROP-IN BOUNDARY: one FullProver whose pool holds two provers on this GPU (K16_DEVICES=0,0 -- one
+    resident key, the second prover one placeholder stream behind the first, yielding waits: what fullprover.cpp sets up by itself),
+    two caller threads, the witness handed over in memory (k16_fullprover_prove_mem) -- the C++ process a Rust service with two
+    workers per GPU is.  prover_handler.rs:244-345 with the mutex of prover_state.rs:21 replaced by the pool."""
+    pkg = os.path.join(ROOT, "keyless-zk-proofs_amd")
+    exe = os.path.join(pkg, "fullprover_harness")
+    if not os.path.exists(exe):
+        return {"error": "fullprover_harness not built"}
+    env = dict(os.environ, K16_DEVICES="0,0", K16_HARNESS_MEM="1")
+    out = subprocess.run([exe, zpath, wpath, str(proofs_per_thread), "2"], capture_output=True, text=True, timeout=900, env=env)
+    lines = out.stdout.splitlines()
+    ok = sum(1 for l in lines if l.startswith("type=0 error=0"))
+    tot = [l for l in lines if l.startswith("elapsed_ms=")]
+    if out.returncode != 0 or ok != 2 * proofs_per_thread or not tot:
+        return {"error": "harness rc=%d, %d proofs ok: %s" % (out.returncode, ok, (out.stderr or out.stdout)[-300:])}
+    elapsed = float(tot[0].split()[0].split("=")[1])
+    return {"proofs_per_s": ok / (elapsed * 1e-3), "proofs": ok, "provers": 2, "caller_threads": 2,
+            "note": "FullProver with K16_DEVICES=0,0 (one resident key, stream offset, yielding waits), k16_fullprover_prove_mem from two "
+                    "threads; includes each prover's first proof"}
+
+
 def verify_leg(ctx, k16, with_oracle):
     """The batched GPU verifier (k16_verify_batch) on toy-circuit proofs made by the GPU prover: the only
     key with a verification key offline; the cost of a Groth16 check does not depend on the circuit (3 pairings + one
@@ -514,6 +536,7 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
             try:
                 out["facade"] = facade_leg(zpath, wpath, max(4, proofs // 2))
                 out["facade_mem"] = facade_leg(zpath, wpath, max(4, proofs // 2), mem=True)
+                out["facade_pool"] = facade_pool_leg(zpath, wpath, max(60, proofs))
             except Exception as e:
                 out["facade"] = {"error": repr(e)}
         if check_with_oracle:

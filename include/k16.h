@@ -95,6 +95,13 @@ int         k16_host_threads(void);
  * serialised inside the call.  Callers that want proofs in parallel use one context per prover (FullProver's K16_DEVICES
  * pool does); all contexts of a process share one host-thread pool (k16_host_threads). */
 int         k16_ctx_create(int device, k16_ctx** out);
+/* The same, behind `stream_offset` (0..7) placeholder streams that the context creates first and keeps until it is destroyed.
+ * ROCm hands hardware queues to streams in creation order and the queues share four dispatch pipes, so the offset decides WHICH
+ * streams of two contexts that work on one GPU take turns on a pipe: with the second prover of a device one stream behind the
+ * first (what FullProver does for K16_DEVICES=0,0) two provers reach 198 instead of 189 proofs/s through the facade (8 of 8
+ * alternating runs, profiles/r06/ab_facade_pool_stream_offset.log); a context that works ALONE wants offset 0.
+ * Results are identical for every offset. */
+int         k16_ctx_create_ex(int device, int stream_offset, k16_ctx** out);
 void        k16_ctx_destroy(k16_ctx* ctx);
 const char* k16_last_error(const k16_ctx* ctx);
 /* Tuning.  K16_OPT_PIPELINED_MSM (value 0/1, default 0): the caller keeps several MSMs in flight on different lanes

@@ -112,6 +112,7 @@ struct k16_ctx {
     };
     Lane lanes[N_LANES];
     int  cur_lane = 0; // lane of the next k16_msm_enqueue*
+    std::vector<hipStream_t> placeholder_streams; // k16_ctx_create_ex: created before the context's own, destroyed with it
     bool yielding_waits = false; // K16_OPT_YIELDING_WAITS: host waits poll + sleep instead of spinning inside the runtime (k16_event_wait)
     hipEvent_t wait_after_memset = nullptr; // one-shot: the next bucket sort waits for this event BEHIND its tables' memset
     void* pinned = nullptr;     // small pinned host staging buffer (coherent, mapped into the device's address space)

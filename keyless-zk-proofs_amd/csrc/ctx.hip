@@ -102,9 +102,12 @@ k16_tuning k16_tuning::from_env()
     return t;
 }
 
-extern "C" int k16_ctx_create(int device, k16_ctx** out)
+extern "C" int k16_ctx_create(int device, k16_ctx** out) { return k16_ctx_create_ex(device, 0, out); }
+
+extern "C" int k16_ctx_create_ex(int device, int stream_offset, k16_ctx** out)
 {
     return k16_guard(nullptr, [&]() -> int {
+    if (stream_offset < 0 || stream_offset > 7) return K16_ERR_ARG;
     if (!out) return K16_ERR_ARG;
     *out  = nullptr;
     int n = 0;
@@ -113,17 +116,19 @@ extern "C" int k16_ctx_create(int device, k16_ctx** out)
     k16_ctx* c = new k16_ctx();
     c->device  = device;
     c->tune    = k16_tuning::from_env(); // the only place the library reads its tuning switches
-    // K16_STREAM_SKEW=a[,b] (round 6 experiment): the n-th context of the process creates (a * n + b) mod 8 placeholder
-    // streams before its own, which shifts the hardware queues (and so the dispatch pipes) its streams land on relative to the
-    // other contexts' -- which streams of two provers sharing a GPU take turns on one pipe
-    if (const char* e = getenv("K16_STREAM_SKEW")) {
-        static std::atomic<int> n_ctx{0};
-        // "a" or "a,b": context n gets (a * n + b) mod 8 placeholders
-        const char* comma = strchr(e, ',');
-        const int   skew  = (n_ctx.fetch_add(1) * atoi(e) + (comma ? atoi(comma + 1) : 0)) & 7;
+    // placeholder streams first (k16_ctx_create_ex; K16_STREAM_SKEW=a[,b] adds (a * n + b) mod 8 for the n-th context of the process:
+    // the round-6 experiment switch): they shift the hardware queues -- and so the dispatch pipes -- this context's
+    // streams land on relative to the contexts made before it
+    {
+        int skew = stream_offset & 7;
+        if (const char* e = getenv("K16_STREAM_SKEW")) {
+            static std::atomic<int> n_ctx{0};
+            const char* comma = strchr(e, ',');
+            skew = (skew + n_ctx.fetch_add(1) * atoi(e) + (comma ? atoi(comma + 1) : 0)) & 7;
+        }
         for (int k = 0; k < skew; k++) {
-            hipStream_t dummy = nullptr;
-            (void)hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking); // (kept for the life of the process)
+            hipStream_t ph = nullptr;
+            if (hipStreamCreateWithFlags(&ph, hipStreamNonBlocking) == hipSuccess) c->placeholder_streams.push_back(ph);
         }
     }
     bool lanes_ok = true;
@@ -190,6 +195,7 @@ extern "C" void k16_ctx_destroy(k16_ctx* c)
         if (kv.second.roots9) (void)hipFree(kv.second.roots9);
     for (auto& kv : c->ntt_tables)
         if (kv.second.stage9) (void)hipFree(kv.second.stage9);
+    for (hipStream_t ph : c->placeholder_streams) (void)hipStreamDestroy(ph);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (int i = 0; i < k16_ctx::PEND_SLOTS; i++)
         if (c->pend_ev[i]) (void)hipEventDestroy(c->pend_ev[i]);

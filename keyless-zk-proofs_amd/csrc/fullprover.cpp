@@ -205,7 +205,13 @@ FullProver::FullProver(const char* _zkeyFileName) : impl(nullptr), state(FullPro
         for (int dev : devs) {
             FullProverImpl::Slot s;
             s.device = dev;
-            if (k16_ctx_create(dev, &s.ctx) != K16_OK) {
+            // the n-th prover of a device sits n placeholder streams behind the first (include/k16.h k16_ctx_create_ex: which streams
+            // of provers that share a GPU take turns on a dispatch pipe; +4.6 % proofs/s for two).  K16_POOL_STREAM_OFFSET=0 disables.
+            int same_dev = 0;
+            for (auto& o : p->slots) same_dev += o.device == dev;
+            const char* off_env = getenv("K16_POOL_STREAM_OFFSET");
+            const int   offset  = (off_env ? atoi(off_env) : 1) * same_dev;
+            if (k16_ctx_create_ex(dev, ((offset % 4) + 4) % 4, &s.ctx) != K16_OK) {
                 fprintf(stderr, "k16 FullProver: no usable MI355X / HIP device %d; the prover has no CPU fallback\n", dev);
                 delete p;
                 return;

@@ -33,7 +33,7 @@ ERR = {0: "OK", -1: "NO_DEVICE", -2: "HIP", -3: "ARG", -4: "IO", -5: "FORMAT", -
 
 # every symbol include/k16.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "k16_runtime_hw_queues", "k16_device_count", "k16_host_threads", "k16_ctx_create", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
+    "k16_runtime_hw_queues", "k16_device_count", "k16_host_threads", "k16_ctx_create", "k16_ctx_create_ex", "k16_ctx_destroy", "k16_last_error", "k16_sync", "k16_stream",
     "k16_dev_alloc", "k16_dev_free", "k16_h2d", "k16_d2h", "k16_host_register", "k16_host_unregister",
     "k16_timer_start", "k16_timer_stop", "k16_kernel_stats_enable", "k16_kernel_stats_reset", "k16_kernel_stats_get",
     "k16_ctx_set_option", "k16_msm", "k16_msm_host", "k16_msm_enqueue", "k16_msm_finish", "k16_msm_finish_group", "k16_msm_pending", "k16_msm_abort_all", "k16_msm_bases_prepare", "k16_msm_enqueue_prepared", "k16_msm_fixed_base_info", "k16_msm_fixed_base_prepare", "k16_msm_enqueue_fixed_base", "k16_msm_set_window_bits", "k16_msm_set_lane", "k16_points_sum",
@@ -67,6 +67,7 @@ def load():
     vp, u64, i32, u32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_uint32, C.c_size_t
     L.k16_runtime_hw_queues.argtypes = [i32]
     L.k16_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.k16_ctx_create_ex.argtypes = [i32, i32, C.POINTER(vp)]
     L.k16_ctx_destroy.argtypes = [vp]
     L.k16_ctx_destroy.restype = None
     L.k16_last_error.argtypes = [vp]
@@ -201,10 +202,11 @@ class DeviceBuffer:
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, stream_offset=0):
+        """stream_offset: k16_ctx_create_ex -- placeholder streams created before the context's own (include/k16.h)"""
         self.L = load()
         h = C.c_void_p()
-        rc = self.L.k16_ctx_create(device, C.byref(h))
+        rc = self.L.k16_ctx_create_ex(device, stream_offset, C.byref(h)) if stream_offset else self.L.k16_ctx_create(device, C.byref(h))
         if rc:
             raise K16Error(rc, "k16_ctx_create(device=%d): no usable HIP device" % device)
         self.h = h

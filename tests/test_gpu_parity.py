@@ -1126,6 +1126,32 @@ def test_compact_witness_hand_off(tmp_path):
         c.close()
 
 
+def test_context_behind_placeholder_streams_gives_the_same_results(toy_paths):
+    """k16_ctx_create_ex (include/k16.h, round 6): a context created behind 1 .. 7 placeholder streams lands on other hardware queues --
+    a placement choice: MSM results and proof bytes equal the oracle's (RS/multiexp.cpp:183-245, RS/groth16.cpp:41-360); an offset
+    outside 0 .. 7 is refused."""
+    import k16
+    zkey, wtns, _ = toy_paths
+    n = 3000
+    bases = ol.gen_points(0, 4, n)
+    scalars = np_scalars(616, n, "full256")
+    want = ol.msm(0, bases, scalars, nthreads=4)[1]
+    z = bytes(32)
+    proof = ol.prove_files(zkey, wtns, z, z)
+    for off in (1, 3, 7):
+        c = k16.Context(0, stream_offset=off)
+        try:
+            assert c.msm(0, bases, scalars)[1] == want
+            p = k16.Prover(c, zkey)
+            assert p.prove_file(wtns, z, z) == proof
+            p.close()
+        finally:
+            c.close()
+    with pytest.raises(k16.K16Error) as e:
+        k16.Context(0, stream_offset=8)
+    assert e.value.rc == -3
+
+
 def test_yielding_waits_give_the_same_results(tmp_path, toy_paths):
     """K16_OPT_YIELDING_WAITS (include/k16.h, round 6): the host waits of k16_msm_finish* and of the prove calls poll + sleep
     instead of spinning inside the runtime -- a scheduling choice of the HOST: MSM results and proof bytes equal the oracle's
