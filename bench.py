@@ -404,7 +404,9 @@ def proof_leg(ctx, k16, torch, dist, rank, world, proofs, check_with_oracle, sca
     n_conc = int(os.environ.get("K16_BENCH_PROVERS", "2"))
     if n_conc > 1:
         import threading
-        others = [k16.Context(ctx_device(ctx)) for _ in range(n_conc - 1)]
+        # (the further provers of this GPU sit i placeholder streams behind the first, as in FullProver's pool: k16_ctx_create_ex)
+        off = int(os.environ.get("K16_BENCH_OTHER_OFFSET", "1"))
+        others = [k16.Context(ctx_device(ctx), stream_offset=((i + 1) * off) % 4) for i in range(n_conc - 1)]
         for c in [ctx] + others:
             c.set_option(k16.OPT_SHARED_GPU, 1)      # what FullProver does for K16_DEVICES=0,0 (include/k16.h)
         provers = [prover] + [k16.Prover(c, zpath) for c in others]
