@@ -147,3 +147,26 @@ def test_bench_weak_mode_two_ranks_overlap_their_exchanges_through_the_c_leg(fak
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["ranks_seen"] == 2 and d["result_checked"] is True and d["scaling"] == "weak"
     assert "k16_rank_comm" in d["config"]["sharding"] and d["config"]["exchange_note"] is None, d["config"]
+
+
+def test_bench_eight_ranks_rehearsal_over_the_double(fake):
+    """The shape of the driver's scaling run at N = 8 -- `bench.py --gpus 8`, default mode, default legs -- with all eight ranks on
+    GPU 0 and the RCCL double as the fabric, at reduced sizes (a 5 % circuit, a 10 % wave key, a 2^22-point sharded MSM) so that it
+    fits the suite's time budget: weak-mode exchange through k16_rank_comm_allgather_start / _finish at world 8, replica proofs on
+    eight ranks, the 64-proof wave spread over them and verified in one batch on rank 0, ONE MSM as eight one-shard ranks + the
+    library's gather and fold.  (The full-size rehearsal: profiles/r06/bench_8ranks_sharing_one_gpu_default_command.json.)"""
+    env = dict(os.environ, K16_BENCH_SHARE_GPU="1", K16_BENCH_PREWARM="1", K16_RCCL_LIB=fake, K16_BENCH_WAVE_SCALE="0.1",
+               K16_BENCH_2P26_LOG2N="22", K16_BENCH_PROVERS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "K16_BENCH_EXCHANGE", "K16_BENCH_NO_CONFIG_LEGS"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1", "--log2n", "16",
+                          "--proofs", "2", "--proof-scale", "0.05", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200,
+                         env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["result_checked"] is True
+    assert "k16_rank_comm" in d["config"]["sharding"] and d["config"]["exchange_note"] is None
+    assert d["proof"]["proofs"] == 16 and d["proof"]["parallelism"].startswith("replicas")
+    w, s5 = d["config4_wave"], d["strong_2p22"]
+    assert w["ranks_seen"] == 8 and w["proofs"] == 64 and w["all_accepted"] and w["wrong_inputs_rejected"] and w["distinct"]
+    assert s5["ranks_seen"] == 8 and s5["shards"] == 8 and s5["result_checked"] is True and "k16_rank_comm_allgather_fold" in s5["entry"]
